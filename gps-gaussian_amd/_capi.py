@@ -1,0 +1,65 @@
+"""ctypes binding of include/gpsgs.h.  No fallback: a missing library is an ImportError with build instructions."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
+
+# every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
+SYMBOLS = (
+    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_forward", "gsr_backward", "gsr_read_header",
+    "gsr_export_state", "cs_forward", "cs_backward",
+)
+
+GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
+_ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "no HIP device"}
+GSR_FLAG_DEBUG = 1
+
+
+class GsrHeader(C.Structure):
+    _fields_ = [("num_rendered", C.c_uint64), ("overflow", C.c_uint32), ("max_tile_count", C.c_uint32),
+                ("num_visible", C.c_uint32), ("reserved", C.c_uint32 * 11)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libgpsgs_hip.so once.  Raises ImportError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gps_gaussian_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C gps-gaussian_amd/csrc`). There is no CPU fallback for this path." % LIB_PATH)
+    l = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, sz, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint
+    l.gpsgs_abi_version.restype = i32
+    l.gpsgs_abi_version.argtypes = []
+    l.gpsgs_build_info.restype = C.c_char_p
+    l.gpsgs_build_info.argtypes = []
+    l.gsr_workspace_bytes.restype = sz
+    l.gsr_workspace_bytes.argtypes = [i32, i32, i32, i64]
+    l.gsr_forward.restype = i32
+    l.gsr_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, sz, i64, u32, vp]
+    l.gsr_backward.restype = i32
+    l.gsr_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                               vp, vp, sz, i64, u32, vp]
+    l.gsr_read_header.restype = i32
+    l.gsr_read_header.argtypes = [vp, C.POINTER(GsrHeader), vp]
+    l.gsr_export_state.restype = i32
+    l.gsr_export_state.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    l.cs_forward.restype = i32
+    l.cs_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    l.cs_backward.restype = i32
+    l.cs_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    if l.gpsgs_abi_version() != 1:
+        raise ImportError("gps_gaussian_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("gps_gaussian_amd: %s failed: %s (%d)" % (what, _ERR.get(rc, "unknown"), rc))

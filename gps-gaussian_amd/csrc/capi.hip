@@ -1,0 +1,158 @@
+// capi.hip -- extern "C" entry points of libgpsgs_hip.so (declared in include/gpsgs.h).
+// Pure enqueue: no allocation, no host synchronisation (except in the explicit *_read_header helper and under
+// GSR_FLAG_DEBUG), so a forward+backward pair can be captured into a hipGraph.
+#include "gsr_common.h"
+
+namespace {
+
+inline uint8_t *at(void *ws, size_t off) { return reinterpret_cast<uint8_t *>(ws) + off; }
+inline const uint8_t *at(const void *ws, size_t off) { return reinterpret_cast<const uint8_t *>(ws) + off; }
+
+inline int check(hipStream_t s, unsigned flags) {
+    if (hipGetLastError() != hipSuccess) return GPSGS_E_LAUNCH;
+    if (flags & GSR_FLAG_DEBUG) {
+        if (hipStreamSynchronize(s) != hipSuccess) return GPSGS_E_LAUNCH;
+        if (hipGetLastError() != hipSuccess) return GPSGS_E_LAUNCH;
+    }
+    return GPSGS_OK;
+}
+
+__global__ void k_export(int P, int T, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ tile_offset, float *depth,
+                         float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P) {
+        const GsrSplat s = splats[i];
+        if (depth) depth[i] = s.depth;
+        if (xy) { xy[2 * i] = s.x; xy[2 * i + 1] = s.y; }
+        if (conic_opacity) { conic_opacity[4 * i] = s.A; conic_opacity[4 * i + 1] = s.B; conic_opacity[4 * i + 2] = s.C; conic_opacity[4 * i + 3] = s.op; }
+        if (rect) { rect[4 * i] = s.rect_lo & 0xffff; rect[4 * i + 1] = s.rect_lo >> 16; rect[4 * i + 2] = s.rect_hi & 0xffff; rect[4 * i + 3] = s.rect_hi >> 16; }
+    }
+    if (i < T && tile_ranges) {
+        const uint32_t a = tile_offset[i], b = tile_offset[i + 1];
+        tile_ranges[2 * i] = b > a ? (int64_t)a : 0;
+        tile_ranges[2 * i + 1] = b > a ? (int64_t)b : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int gpsgs_abi_version(void) { return GPSGS_ABI_VERSION; }
+
+extern "C" const char *gpsgs_build_info(void) { return "gfx950 hipcc " __VERSION__ " built " __DATE__; }
+
+extern "C" size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity) {
+    if (P < 0 || width < 0 || height < 0 || instance_capacity < 0) return 0;
+    return gsr_layout(P, width, height, instance_capacity).total;
+}
+
+extern "C" int gsr_forward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                           const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                           const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                           void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream) {
+    if (P < 0 || width <= 0 || height <= 0 || instance_capacity < 0 || instance_capacity > 0x7fffffffLL) return GPSGS_E_INVALID;
+    if (width > 65535 * GSR_TILE || height > 65535 * GSR_TILE) return GPSGS_E_INVALID;
+    if (!out_color || !workspace) return GPSGS_E_INVALID;
+    if (P > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !projmatrix || !bg || !radii))
+        return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    GsrHeader *hdr = reinterpret_cast<GsrHeader *>(at(workspace, L.header));
+    uint32_t *tile_count = reinterpret_cast<uint32_t *>(at(workspace, L.tile_count));
+    uint32_t *tile_offset = reinterpret_cast<uint32_t *>(at(workspace, L.tile_offset));
+    uint32_t *tile_cursor = reinterpret_cast<uint32_t *>(at(workspace, L.tile_cursor));
+    GsrSplat *splats = reinterpret_cast<GsrSplat *>(at(workspace, L.splats));
+    uint64_t *keys = reinterpret_cast<uint64_t *>(at(workspace, L.keys));
+    uint32_t *point_list = reinterpret_cast<uint32_t *>(at(workspace, L.point_list));
+    float *final_T = reinterpret_cast<float *>(at(workspace, L.final_T));
+    uint32_t *n_contrib = reinterpret_cast<uint32_t *>(at(workspace, L.n_contrib));
+
+    // header + tile_count are adjacent: one memset
+    if (hipMemsetAsync(hdr, 0, L.tile_offset - L.header, s) != hipSuccess) return GPSGS_E_LAUNCH;
+    if (P == 0) {  // upstream returns its zero-initialised image (NOT the background) when there is nothing to draw
+        if (hipMemsetAsync(out_color, 0, sizeof(float) * 3 * (size_t)width * height, s) != hipSuccess) return GPSGS_E_LAUNCH;
+        if (hipMemsetAsync(tile_offset, 0, (size_t)(L.T + 1) * 4, s) != hipSuccess) return GPSGS_E_LAUNCH;
+        return check(s, flags);
+    }
+    GsrFwdParams q;
+    q.P = P; q.W = width; q.H = height; q.gx = L.gx; q.gy = L.gy;
+    q.means3D = means3D; q.colors = colors; q.opacities = opacities; q.scales = scales; q.rotations = rotations;
+    q.scale_modifier = scale_modifier; q.tanfovx = tanfovx; q.tanfovy = tanfovy;
+    q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity;
+
+    int rc;
+    gsr_launch_preprocess(q, splats, tile_count, hdr, s);
+    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+    gsr_launch_scan(tile_count, tile_offset, tile_cursor, L.T, instance_capacity, hdr, s);
+    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+    gsr_launch_scatter(P, L.gx, splats, tile_cursor, keys, instance_capacity, hdr, s);
+    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+    gsr_launch_sort(L.T, tile_offset, keys, point_list, hdr, s);
+    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+    gsr_launch_composite_fwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+    return check(s, flags);
+}
+
+extern "C" int gsr_backward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                            const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                            const float *viewmatrix, const float *projmatrix, const float *bg, const int *radii,
+                            const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                            float *dL_dscales, float *dL_drotations, void *workspace, size_t workspace_bytes,
+                            int64_t instance_capacity, unsigned flags, void *stream) {
+    (void)colors; (void)opacities;  // already folded into the splat records of the workspace
+    if (P < 0 || width <= 0 || height <= 0 || instance_capacity < 0) return GPSGS_E_INVALID;
+    if (P == 0) return GPSGS_OK;
+    if (!means3D || !scales || !rotations || !viewmatrix || !projmatrix || !bg || !radii || !dL_dpix || !dL_dmeans3D || !dL_dmeans2D ||
+        !dL_dcolors || !dL_dopacity || !dL_dscales || !dL_drotations || !workspace)
+        return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const GsrHeader *hdr = reinterpret_cast<const GsrHeader *>(at(workspace, L.header));
+    const uint32_t *tile_offset = reinterpret_cast<const uint32_t *>(at(workspace, L.tile_offset));
+    const GsrSplat *splats = reinterpret_cast<const GsrSplat *>(at(workspace, L.splats));
+    const uint32_t *point_list = reinterpret_cast<const uint32_t *>(at(workspace, L.point_list));
+    const float *final_T = reinterpret_cast<const float *>(at(workspace, L.final_T));
+    const uint32_t *n_contrib = reinterpret_cast<const uint32_t *>(at(workspace, L.n_contrib));
+    GsrGradAcc *gacc = reinterpret_cast<GsrGradAcc *>(at(workspace, L.gacc));
+
+    if (hipMemsetAsync(gacc, 0, (size_t)P * sizeof(GsrGradAcc), s) != hipSuccess) return GPSGS_E_LAUNCH;
+    int rc;
+    gsr_launch_composite_bwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, dL_dpix, final_T, n_contrib, gacc, hdr, s);
+    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+    GsrBwdParams b;
+    b.P = P; b.W = width; b.H = height;
+    b.means3D = means3D; b.scales = scales; b.rotations = rotations;
+    b.scale_modifier = scale_modifier; b.tanfovx = tanfovx; b.tanfovy = tanfovy;
+    b.view = viewmatrix; b.proj = projmatrix; b.radii = radii;
+    b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
+    b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
+    gsr_launch_preprocess_bwd(b, gacc, s);
+    return check(s, flags);
+}
+
+extern "C" int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream) {
+    if (!workspace || !host_out) return GPSGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(host_out, workspace, sizeof(GsrHeader), hipMemcpyDeviceToHost, s) != hipSuccess) return GPSGS_E_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return GPSGS_E_LAUNCH;
+    return GPSGS_OK;
+}
+
+extern "C" int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, float *depth, float *xy,
+                                float *conic_opacity, int *rect, int64_t *tile_ranges, uint32_t *point_list, float *final_T,
+                                uint32_t *n_contrib, void *stream) {
+    if (!workspace || P < 0 || width <= 0 || height <= 0) return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = P > L.T ? P : L.T;
+    if (n > 0)
+        hipLaunchKernelGGL(k_export, dim3((n + 255) / 256), dim3(256), 0, s, P, L.T, reinterpret_cast<const GsrSplat *>(at(workspace, L.splats)),
+                           reinterpret_cast<const uint32_t *>(at(workspace, L.tile_offset)), depth, xy, conic_opacity, rect, tile_ranges);
+    const size_t npix = (size_t)width * height;
+    if (point_list && instance_capacity > 0)
+        (void)hipMemcpyAsync(point_list, at(workspace, L.point_list), (size_t)instance_capacity * 4, hipMemcpyDeviceToDevice, s);
+    if (final_T) (void)hipMemcpyAsync(final_T, at(workspace, L.final_T), npix * 4, hipMemcpyDeviceToDevice, s);
+    if (n_contrib) (void)hipMemcpyAsync(n_contrib, at(workspace, L.n_contrib), npix * 4, hipMemcpyDeviceToDevice, s);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}

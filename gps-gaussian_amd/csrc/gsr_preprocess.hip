@@ -1,0 +1,279 @@
+// gsr_preprocess.hip -- per-Gaussian stages of the rasteriser for gfx950 (HBM-bound maps, one thread per Gaussian).
+//
+//   k_preprocess      : cull, project, 3D covariance -> EWA 2D covariance -> conic, radius, tile rect; writes the
+//                       48-byte splat record + radii and counts the Gaussian into every tile of its rect.
+//                       Replaces upstream preprocessCUDA (+ the tiles_touched half of the binning); semantics:
+//                       SURVEY.md section 9.1; call-site configuration /root/reference/gaussian_renderer/__init__.py:36-62.
+//   k_preprocess_bwd  : conic/mean2D/colour partial sums -> dL/d(mean3D, scale, rotation, ...) (upstream
+//                       computeCov2DCUDA + preprocessCUDA backward fused).  cov3D is recomputed
+//                       from scale/rotation instead of being stored (saves 48 B/Gaussian of HBM round trip).
+//
+// This translation unit is compiled with -ffp-contract=off and correctly-rounded div/sqrt: every discrete decision
+// (near cull, radius, tile rect, depth bits used for ordering) is then bit-identical to the fp32 CPU oracle.
+#include "gsr_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct Cam {
+    float v[16];
+    float p[16];
+};
+
+__device__ __forceinline__ Cam load_cam(const float *__restrict__ view, const float *__restrict__ proj) {
+    Cam c;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { c.v[i] = view[i]; c.p[i] = proj[i]; }  // wave-uniform -> scalar loads
+    return c;
+}
+
+__device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, float R[3][3]) {
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R diag(s)^2 R^T as M^T M with M[k][i] = s_k R[i][k]
+__device__ __forceinline__ void cov3d(const float s[3], const float R[3][3], float c6[6]) {
+    float M[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) M[k][i] = s[k] * R[i][k];
+#define GSR_SIG(i, j) (M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j])
+    c6[0] = GSR_SIG(0, 0); c6[1] = GSR_SIG(0, 1); c6[2] = GSR_SIG(0, 2);
+    c6[3] = GSR_SIG(1, 1); c6[4] = GSR_SIG(1, 2); c6[5] = GSR_SIG(2, 2);
+#undef GSR_SIG
+}
+
+struct Ewa {
+    float t[3], xmul, ymul, T[2][3];
+};
+
+__device__ __forceinline__ Ewa ewa_setup(const float pv[3], const float *v, float fx, float fy, float tanx, float tany) {
+    Ewa e;
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    const float txtz = pv[0] / pv[2], tytz = pv[1] / pv[2];
+    e.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    e.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    float cx = txtz < -limx ? -limx : txtz; cx = cx > limx ? limx : cx;
+    float cy = tytz < -limy ? -limy : tytz; cy = cy > limy ? limy : cy;
+    e.t[0] = cx * pv[2];
+    e.t[1] = cy * pv[2];
+    e.t[2] = pv[2];
+    const float J00 = fx / e.t[2];
+    const float J02 = -(fx * e.t[0]) / (e.t[2] * e.t[2]);
+    const float J11 = fy / e.t[2];
+    const float J12 = -(fy * e.t[1]) / (e.t[2] * e.t[2]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        e.T[0][j] = J00 * v[j * 4 + 0] + J02 * v[j * 4 + 2];
+        e.T[1][j] = J11 * v[j * 4 + 1] + J12 * v[j * 4 + 2];
+    }
+    return e;
+}
+
+__device__ __forceinline__ void cov2d(const Ewa &e, const float c6[6], float &a, float &b, float &c) {
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float V[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int m = 0; m < 2; m++) V[k][m] = S[k][0] * e.T[m][0] + S[k][1] * e.T[m][1] + S[k][2] * e.T[m][2];
+    a = e.T[0][0] * V[0][0] + e.T[0][1] * V[1][0] + e.T[0][2] * V[2][0] + 0.3f;
+    b = e.T[0][0] * V[0][1] + e.T[0][1] * V[1][1] + e.T[0][2] * V[2][1];
+    c = e.T[1][0] * V[0][1] + e.T[1][1] * V[1][1] + e.T[1][2] * V[2][1] + 0.3f;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats,
+                                                    uint32_t *__restrict__ tile_count, GsrHeader *__restrict__ hdr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= q.P) return;
+    const Cam cam = load_cam(q.view, q.proj);
+    const float p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
+    const float col[3] = {q.colors[3 * (size_t)i], q.colors[3 * (size_t)i + 1], q.colors[3 * (size_t)i + 2]};
+    const float op = q.opacities[i];
+
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = make_float4(0.f, op, col[0], col[1]);
+    float o2x = col[2], o2y = 0.f;
+    uint32_t rlo = 0, rhi = 0;
+    int radius = 0;
+
+    float pv[3];
+    pv[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+    pv[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+    pv[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+    if (pv[2] > 0.2f) {  // near cull: the only frustum test upstream applies
+        const float phx = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
+        const float phy = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
+        const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
+        const float pw = 1.f / (phw + 0.0000001f);
+        const float ppx = phx * pw, ppy = phy * pw;
+        const float fx = (float)q.W / (2.f * q.tanfovx), fy = (float)q.H / (2.f * q.tanfovy);
+
+        const float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
+        const float sc[3] = {q.scale_modifier * q.scales[3 * (size_t)i], q.scale_modifier * q.scales[3 * (size_t)i + 1],
+                             q.scale_modifier * q.scales[3 * (size_t)i + 2]};
+        float R[3][3], c6[6];
+        quat_to_R(rot.x, rot.y, rot.z, rot.w, R);
+        cov3d(sc, R, c6);
+        const Ewa e = ewa_setup(pv, cam.v, fx, fy, q.tanfovx, q.tanfovy);
+        float a, b, c;
+        cov2d(e, c6, a, b, c);
+        const float det = a * c - b * b;
+        if (det != 0.f) {
+            const float det_inv = 1.f / det;
+            const float mid = 0.5f * (a + c);
+            float disc = mid * mid - det;
+            if (disc < 0.1f) disc = 0.1f;
+            const float l1 = mid + sqrtf(disc), l2 = mid - sqrtf(disc);
+            const float my_radius = ceilf(3.f * sqrtf(l1 > l2 ? l1 : l2));
+            const float px = ((ppx + 1.f) * (float)q.W - 1.f) * 0.5f;
+            const float py = ((ppy + 1.f) * (float)q.H - 1.f) * 0.5f;
+            const int r0x = clampi((int)((px - my_radius) / 16.f), 0, q.gx);
+            const int r0y = clampi((int)((py - my_radius) / 16.f), 0, q.gy);
+            const int r1x = clampi((int)((px + my_radius + 15.f) / 16.f), 0, q.gx);
+            const int r1y = clampi((int)((py + my_radius + 15.f) / 16.f), 0, q.gy);
+            if ((r1x - r0x) * (r1y - r0y) != 0) {
+                radius = (int)my_radius;
+                o0 = make_float4(px, py, c * det_inv, -b * det_inv);
+                o1.x = a * det_inv;
+                o2y = pv[2];
+                rlo = (uint32_t)r0x | ((uint32_t)r0y << 16);
+                rhi = (uint32_t)r1x | ((uint32_t)r1y << 16);
+                for (int ty = r0y; ty < r1y; ty++)
+                    for (int tx = r0x; tx < r1x; tx++) atomicAdd(&tile_count[ty * q.gx + tx], 1u);
+            }
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(splats + i);
+    dst[0] = o0;
+    dst[1] = o1;
+    dst[2] = make_float4(o2x, o2y, __uint_as_float(rlo), __uint_as_float(rhi));
+    q.radii[i] = radius;
+}
+
+__global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrGradAcc *__restrict__ gacc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= q.P) return;
+    float dm[3] = {0.f, 0.f, 0.f}, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
+    if (q.radii[i] > 0) {
+        const Cam cam = load_cam(q.view, q.proj);
+        const float4 *g4 = reinterpret_cast<const float4 *>(gacc + i);
+        const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2];
+        dcol[0] = g0.x; dcol[1] = g0.y; dcol[2] = g0.z;
+        dm2[0] = g0.w; dm2[1] = g1.x;
+        const float dxx = g1.y, dxy = g1.z, dyy = g1.w;
+        dop = g2.x;
+
+        const float p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
+        const float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
+        const float sv[3] = {q.scale_modifier * q.scales[3 * (size_t)i], q.scale_modifier * q.scales[3 * (size_t)i + 1],
+                             q.scale_modifier * q.scales[3 * (size_t)i + 2]};
+        float Rm[3][3], c6[6];
+        quat_to_R(rot.x, rot.y, rot.z, rot.w, Rm);
+        cov3d(sv, Rm, c6);
+        float pv[3];
+        pv[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+        pv[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+        pv[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+        const float fx = (float)q.W / (2.f * q.tanfovx), fy = (float)q.H / (2.f * q.tanfovy);
+        const Ewa e = ewa_setup(pv, cam.v, fx, fy, q.tanfovx, q.tanfovy);
+        float a, b, c;
+        cov2d(e, c6, a, b, c);
+
+        // conic -> cov2D (a,b,c)
+        const float denom = a * c - b * b;
+        const float d2inv = 1.f / (denom * denom + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f, dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float(*T)[3] = e.T;
+        if (d2inv != 0.f) {
+            dL_da = d2inv * (-c * c * dxx + 2.f * b * c * dxy + (denom - a * c) * dyy);
+            dL_dc = d2inv * (-a * a * dyy + 2.f * a * b * dxy + (denom - a * c) * dxx);
+            dL_db = d2inv * 2.f * (b * c * dxx - (denom + 2.f * b * b) * dxy + a * b * dyy);
+            dc6[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+            dc6[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+            dc6[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+            dc6[1] = 2.f * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2.f * T[1][0] * T[1][1] * dL_dc;
+            dc6[2] = 2.f * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2.f * T[1][0] * T[1][2] * dL_dc;
+            dc6[4] = 2.f * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2.f * T[1][1] * T[1][2] * dL_dc;
+        }
+        // cov2D = T Sigma T^T -> dL/dT -> dL/dJ -> dL/dt -> mean3D (through Rw^T)
+        const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float dT[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float s0 = T[0][0] * S[j][0] + T[0][1] * S[j][1] + T[0][2] * S[j][2];
+            const float s1 = T[1][0] * S[j][0] + T[1][1] * S[j][1] + T[1][2] * S[j][2];
+            dT[0][j] = 2.f * s0 * dL_da + s1 * dL_db;
+            dT[1][j] = 2.f * s1 * dL_dc + s0 * dL_db;
+        }
+        const float *v = cam.v;
+        const float dJ00 = dT[0][0] * v[0] + dT[0][1] * v[4] + dT[0][2] * v[8];
+        const float dJ02 = dT[0][0] * v[2] + dT[0][1] * v[6] + dT[0][2] * v[10];
+        const float dJ11 = dT[1][0] * v[1] + dT[1][1] * v[5] + dT[1][2] * v[9];
+        const float dJ12 = dT[1][0] * v[2] + dT[1][1] * v[6] + dT[1][2] * v[10];
+        const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = e.xmul * -fx * tz2 * dJ02;
+        const float dty = e.ymul * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * e.t[0]) * tz3 * dJ02 + (2.f * fy * e.t[1]) * tz3 * dJ12;
+        dm[0] = v[0] * dtx + v[1] * dty + v[2] * dtz;
+        dm[1] = v[4] * dtx + v[5] * dty + v[6] * dtz;
+        dm[2] = v[8] * dtx + v[9] * dty + v[10] * dtz;
+
+        // mean2D (NDC-scaled) -> mean3D through p_hom / (w + 1e-7)
+        const float *pr = cam.p;
+        const float mhw = pr[3] * p[0] + pr[7] * p[1] + pr[11] * p[2] + pr[15];
+        const float mw = 1.f / (mhw + 0.0000001f);
+        const float mul1 = (pr[0] * p[0] + pr[4] * p[1] + pr[8] * p[2] + pr[12]) * mw * mw;
+        const float mul2 = (pr[1] * p[0] + pr[5] * p[1] + pr[9] * p[2] + pr[13]) * mw * mw;
+        dm[0] += (pr[0] * mw - pr[3] * mul1) * dm2[0] + (pr[1] * mw - pr[3] * mul2) * dm2[1];
+        dm[1] += (pr[4] * mw - pr[7] * mul1) * dm2[0] + (pr[5] * mw - pr[7] * mul2) * dm2[1];
+        dm[2] += (pr[8] * mw - pr[11] * mul1) * dm2[0] + (pr[9] * mw - pr[11] * mul2) * dm2[1];
+
+        // cov3D -> scale, rotation: Sigma = R D R^T, D = diag(s^2); dL/dR = 2 G R D; dL/ds_k = 2 s_k (R^T G R)_kk
+        const float Gs[3][3] = {{dc6[0], 0.5f * dc6[1], 0.5f * dc6[2]},
+                                {0.5f * dc6[1], dc6[3], 0.5f * dc6[4]},
+                                {0.5f * dc6[2], 0.5f * dc6[4], dc6[5]}};
+        float GR[3][3], dR[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) GR[r][k] = Gs[r][0] * Rm[0][k] + Gs[r][1] * Rm[1][k] + Gs[r][2] * Rm[2][k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float rtgr = Rm[0][k] * GR[0][k] + Rm[1][k] * GR[1][k] + Rm[2][k] * GR[2][k];
+            dsc[k] = 2.f * sv[k] * rtgr * q.scale_modifier;
+#pragma unroll
+            for (int r = 0; r < 3; r++) dR[r][k] = 2.f * GR[r][k] * sv[k] * sv[k];
+        }
+        const float qr = rot.x, qx = rot.y, qy = rot.z, qz = rot.w;
+        dq[0] = 2.f * (qz * (dR[1][0] - dR[0][1]) + qy * (dR[0][2] - dR[2][0]) + qx * (dR[2][1] - dR[1][2]));
+        dq[1] = 2.f * (qy * (dR[0][1] + dR[1][0]) + qz * (dR[0][2] + dR[2][0]) + qr * (dR[2][1] - dR[1][2])) - 4.f * qx * (dR[1][1] + dR[2][2]);
+        dq[2] = 2.f * (qx * (dR[0][1] + dR[1][0]) + qr * (dR[0][2] - dR[2][0]) + qz * (dR[1][2] + dR[2][1])) - 4.f * qy * (dR[0][0] + dR[2][2]);
+        dq[3] = 2.f * (qr * (dR[1][0] - dR[0][1]) + qx * (dR[0][2] + dR[2][0]) + qy * (dR[1][2] + dR[2][1])) - 4.f * qz * (dR[0][0] + dR[1][1]);
+    }
+    const size_t i3 = 3 * (size_t)i;
+    q.dL_dmeans3D[i3] = dm[0]; q.dL_dmeans3D[i3 + 1] = dm[1]; q.dL_dmeans3D[i3 + 2] = dm[2];
+    q.dL_dmeans2D[i3] = dm2[0]; q.dL_dmeans2D[i3 + 1] = dm2[1]; q.dL_dmeans2D[i3 + 2] = 0.f;
+    q.dL_dcolors[i3] = dcol[0]; q.dL_dcolors[i3 + 1] = dcol[1]; q.dL_dcolors[i3 + 2] = dcol[2];
+    q.dL_dopacity[i] = dop;
+    q.dL_dscales[i3] = dsc[0]; q.dL_dscales[i3 + 1] = dsc[1]; q.dL_dscales[i3 + 2] = dsc[2];
+    *reinterpret_cast<float4 *>(q.dL_drotations + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+}
+
+}  // namespace
+
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *tile_count, GsrHeader *hdr, hipStream_t s) {
+    if (p.P <= 0) return;
+    hipLaunchKernelGGL(k_preprocess, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, tile_count, hdr);
+}
+
+void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrGradAcc *gacc, hipStream_t s) {
+    if (p.P <= 0) return;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, gacc);
+}

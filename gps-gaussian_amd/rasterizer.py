@@ -1,0 +1,264 @@
+"""Drop-in replacement for the `diff_gaussian_rasterization` Python module on MI355X.
+
+Mirrors the interface the reference binds at /root/reference/gaussian_renderer/__init__.py:14,36-62:
+`GaussianRasterizationSettings` (12-field NamedTuple, no `antialiasing`), `GaussianRasterizer(raster_settings)` whose
+call returns the 2-tuple `(color[3,H,W], radii[P])`, and the autograd contract of upstream's `_RasterizeGaussians`
+(gradients for means3D, means2D, colors_precomp, opacities, scales, rotations; None for the rest) -- SURVEY.md section 8b.
+
+All arithmetic happens in libgpsgs_hip.so (hand-written gfx950 kernels) through the C-ABI of include/gpsgs.h.
+There is NO eager/CPU fallback: non-GPU tensors or a missing library raise.
+
+Host-side design notes (MI355X-first, not a translation of upstream's C++ glue):
+  * one workspace tensor per forward replaces upstream's three resizable byte buffers and travels to backward in ctx;
+  * upstream blocks on a D2H copy of `num_rendered` in the middle of every forward to size its sort buffers.  Here the
+    whole forward is enqueued against an instance capacity learnt from previous calls; the kernels record the R they
+    needed + an overflow flag in the workspace header.  `GPSGS_CHECK=sync` (default) waits for that 64-byte header at
+    the END of the forward (no bubble inside the pipeline) and transparently re-runs with a larger capacity on
+    overflow, so results are always exact.  `GPSGS_CHECK=deferred` never blocks: the header lands in pinned memory
+    and is examined on the next call into this module; an overflow then raises (capacity grows for later calls).
+"""
+import ctypes as C
+import os
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---- capacity policy --------------------------------------------------------------------------------------------
+_MIN_CAP = 1 << 16
+_state = {}  # device index -> dict(ratio=instances per Gaussian seen so far, pending=[(event, pinned_header, P)])
+
+
+def _dev_state(dev):
+    st = _state.get(dev.index)
+    if st is None:
+        st = _state[dev.index] = dict(ratio=4.0, floor=_MIN_CAP, pending=[])
+    return st
+
+
+def _capacity_for(st, P):
+    # generous: 288 GB of HBM3E means 12 B/instance of slack is free; 2x the worst ratio seen, never below the floor
+    return int(min(max(st["floor"], int(P * st["ratio"] * 2.0) + 4096), 0x7fffffff))
+
+
+def _check_mode():
+    m = os.environ.get("GPSGS_CHECK", "sync")
+    if m not in ("sync", "deferred"):
+        raise ValueError("GPSGS_CHECK must be 'sync' or 'deferred'")
+    return m
+
+
+def _drain_pending(st, block=False):
+    keep = []
+    for ev, hdr, P in st["pending"]:
+        if block:
+            ev.synchronize()
+        if ev.query():
+            R, overflow = int(hdr[0]), int(hdr[1]) & 0xffffffff
+            _learn(st, R, P)
+            if overflow:
+                st["pending"] = []
+                raise RuntimeError(
+                    "gps_gaussian_amd: a previous rasteriser call (GPSGS_CHECK=deferred) needed %d instances, more than its "
+                    "capacity; that image was not rendered. Capacity has been raised; re-run, or use GPSGS_CHECK=sync." % R)
+        else:
+            keep.append((ev, hdr, P))
+    st["pending"] = keep
+
+
+def _learn(st, R, P):
+    if P > 0:
+        st["ratio"] = max(st["ratio"], R / P)
+    st["floor"] = max(st["floor"], min(int(R * 1.25) + 4096, 0x7fffffff))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _prep(t, name, shape_tail, device):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a tensor" % name)
+    if t.device != device:
+        raise RuntimeError("gps_gaussian_amd: %s is on %s but means3D is on %s (no CPU path exists)" % (name, t.device, device))
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    if shape_tail is not None and (t.dim() < 1 or tuple(t.shape[1:]) != shape_tail):
+        raise RuntimeError("%s must have dimensions (num_points, %s)" % (name, ", ".join(map(str, shape_tail))))
+    return t
+
+
+def _cam(t, n, device):
+    # H1: in training the camera tensors arrive as pinned CPU tensors, in the test scripts as GPU tensors
+    t = t.detach().to(device=device, dtype=torch.float32, non_blocking=True).contiguous().reshape(-1)
+    if t.numel() != n:
+        raise RuntimeError("camera tensor must have %d elements" % n)
+    return t
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        lib = _capi.lib()
+        if not means3D.is_cuda:
+            raise RuntimeError("gps_gaussian_amd: rasteriser inputs must live on a GPU (no CPU fallback)")
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        dev = means3D.device
+        P = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        m3 = _prep(means3D, "means3D", (3,), dev)
+        col = _prep(colors_precomp, "colors_precomp", (3,), dev)
+        opa = _prep(opacities, "opacities", None, dev).reshape(-1)
+        sca = _prep(scales, "scales", (3,), dev)
+        rot = _prep(rotations, "rotations", (4,), dev)
+        if not (col.shape[0] == opa.shape[0] == sca.shape[0] == rot.shape[0] == P):
+            raise RuntimeError("all per-Gaussian inputs must have num_points rows")
+        view = _cam(rs.viewmatrix, 16, dev)
+        proj = _cam(rs.projmatrix, 16, dev)
+        bg = _cam(rs.bg, 3, dev)
+        flags = _capi.GSR_FLAG_DEBUG if rs.debug else 0
+        mode = _check_mode()
+        st = _dev_state(dev)
+        with torch.cuda.device(dev):
+            _drain_pending(st)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            cap = _capacity_for(st, P)
+            while True:
+                nbytes = lib.gsr_workspace_bytes(P, W, H, cap)
+                ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+                rc = lib.gsr_forward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
+                                     float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),
+                                     _ptr(radii), _ptr(ws), nbytes, cap, flags, stream)
+                _capi.check(rc, "gsr_forward")
+                if P == 0:
+                    break
+                hdr = torch.empty((2,), dtype=torch.int64).pin_memory()
+                hdr.copy_(ws[:16].view(torch.int64), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                if mode == "deferred":
+                    st["pending"].append((ev, hdr, P))
+                    break
+                ev.synchronize()
+                R, overflow = int(hdr[0]), int(hdr[1]) & 0xffffffff
+                _learn(st, R, P)
+                if not overflow:
+                    break
+                cap = _capacity_for(st, P)  # grown by _learn; re-run the whole (cheap) forward
+        ctx.raster_settings = rs
+        ctx.cap = cap
+        ctx.save_for_backward(m3, col, opa, sca, rot, view, proj, bg, radii, ws)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        rs = ctx.raster_settings
+        lib = _capi.lib()
+        m3, col, opa, sca, rot, view, proj, bg, radii, ws = ctx.saved_tensors
+        dev = m3.device
+        P = m3.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        g = grad_out_color.detach().to(dtype=torch.float32).contiguous()  # H3: may arrive non-contiguous
+        with torch.cuda.device(dev):
+            st = _dev_state(dev)
+            _drain_pending(st, block=(_check_mode() == "deferred"))
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            d_m3 = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            d_col = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            d_op = torch.empty((P, 1), dtype=torch.float32, device=dev)
+            d_sc = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
+            if P > 0:
+                rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
+                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
+                                      _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
+                                      ws.numel(), ctx.cap, _capi.GSR_FLAG_DEBUG if rs.debug else 0, stream)
+                _capi.check(rc, "gsr_backward")
+        # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+        return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if shs is not None:
+            raise NotImplementedError(
+                "gps_gaussian_amd: spherical-harmonics colours are outside the GPS-Gaussian hot path (the reference always "
+                "passes colors_precomp, gaussian_renderer/__init__.py:54-62)")
+        if cov3D_precomp is not None:
+            raise NotImplementedError(
+                "gps_gaussian_amd: precomputed 3D covariances are outside the GPS-Gaussian hot path (the reference always "
+                "passes scales+rotations, gaussian_renderer/__init__.py:54-62)")
+        return rasterize_gaussians(means3D, means2D, None, colors_precomp, opacities, scales, rotations, None,
+                                   self.raster_settings)
+
+
+def last_stats(device=None):
+    """Capacity-policy state (instances-per-Gaussian ratio seen, capacity floor) for diagnostics."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return dict(_dev_state(dev), pending=len(_dev_state(dev)["pending"]))
+
+
+def export_state(ws, P, W, H, cap):
+    """Debug/parity helper: unpack a forward's workspace into tensors (depth, xy, conic_opacity, rect, ranges, ...)."""
+    lib = _capi.lib()
+    dev = ws.device
+    hdr = ws[:16].view(torch.int64).cpu()
+    R = int(hdr[0])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    out = dict(
+        depth=torch.empty(P, device=dev), xy=torch.empty(P, 2, device=dev), conic_opacity=torch.empty(P, 4, device=dev),
+        rect=torch.empty(P, 4, dtype=torch.int32, device=dev), ranges=torch.empty(gx * gy, 2, dtype=torch.int64, device=dev),
+        point_list=torch.empty(max(cap, 1), dtype=torch.int32, device=dev), final_T=torch.empty(H, W, device=dev),
+        n_contrib=torch.empty(H, W, dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        rc = lib.gsr_export_state(_ptr(ws), P, W, H, cap, _ptr(out["depth"]), _ptr(out["xy"]), _ptr(out["conic_opacity"]),
+                                  _ptr(out["rect"]), _ptr(out["ranges"]), _ptr(out["point_list"]), _ptr(out["final_T"]),
+                                  _ptr(out["n_contrib"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _capi.check(rc, "gsr_export_state")
+    torch.cuda.synchronize(dev)
+    out["point_list"] = out["point_list"][:R]
+    out["num_rendered"] = R
+    out["overflow"] = int(hdr[1]) & 0xffffffff
+    return out

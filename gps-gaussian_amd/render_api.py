@@ -1,0 +1,57 @@
+"""render(data, idx, ...) and pts2render(data, bg_color) with the reference's signatures and semantics.
+
+Host-side mirror of /root/reference/gaussian_renderer/__init__.py:17-67 (`render`) and
+/root/reference/lib/GaussianRender.py:6-40 (`pts2render`).  The reference's own two files also run unmodified against
+the drop-in `diff_gaussian_rasterization` shim; these mirrors exist so that callers (bench, tests, the DDP launcher)
+do not need /root/reference on the path, and they read the camera scalars without per-sample device syncs when the
+tensors already live on the host.
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def _scalar(x):
+    return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
+
+
+def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color):
+    """Render one novel view.  Same arguments and return value as the reference's render(): returns image [3,H,W]."""
+    nv = data['novel_view']
+    bg = torch.tensor(bg_color, dtype=torch.float32, device=pts_xyz.device)
+    screenspace_points = torch.zeros_like(pts_xyz, dtype=torch.float32, requires_grad=True, device=pts_xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(nv['height'][idx]), image_width=int(nv['width'][idx]),
+        tanfovx=math.tan(_scalar(nv['FovX'][idx]) * 0.5), tanfovy=math.tan(_scalar(nv['FovY'][idx]) * 0.5),
+        bg=bg, scale_modifier=1.0, viewmatrix=nv['world_view_transform'][idx], projmatrix=nv['full_proj_transform'][idx],
+        sh_degree=3, campos=nv['camera_center'][idx], prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    rendered_image, _ = rasterizer(means3D=pts_xyz, means2D=screenspace_points, shs=None, colors_precomp=pts_rgb,
+                                   opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+    return rendered_image
+
+
+def pts2render(data, bg_color):
+    """Same contract as the reference's pts2render(): writes data['novel_view']['img_pred'] = [B,3,H,W]."""
+    bs = data['lmain']['img'].shape[0]
+    out = []
+    for i in range(bs):
+        parts = [[], [], [], [], []]
+        for view in ('lmain', 'rmain'):
+            d = data[view]
+            valid = d['pts_valid'][i, :]
+            maps = (d['xyz'][i], d['img'][i].permute(1, 2, 0).reshape(-1, 3), d['rot_maps'][i].permute(1, 2, 0).reshape(-1, 4),
+                    d['scale_maps'][i].permute(1, 2, 0).reshape(-1, 3), d['opacity_maps'][i].permute(1, 2, 0).reshape(-1, 1))
+            for lst, m in zip(parts, maps):
+                lst.append(m[valid])
+        xyz, rgb, rot, scale, opacity = (torch.cat(p, dim=0) for p in parts)
+        rgb = rgb * 0.5 + 0.5
+        out.append(render(data, i, xyz, rgb, rot, scale, opacity, bg_color=bg_color).unsqueeze(0))
+    data['novel_view']['img_pred'] = torch.cat(out, dim=0)
+    return data

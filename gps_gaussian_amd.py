@@ -1,0 +1,11 @@
+"""Import alias: the package directory is named `gps-gaussian_amd/` (not a valid Python identifier), so
+`import gps_gaussian_amd` loads it from there.  Nothing else lives in this file."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gps-gaussian_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,108 @@
+/*
+ * gpsgs.h -- C ABI of the MI355X-native render hot path of GPS-Gaussian (libgpsgs_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types, no exceptions, no allocation and no
+ * host synchronisation inside any entry point (all are hipGraph-capture safe).  Every function returns 0 on
+ * success or a negative GPSGS_E_* code.  All pointers are DEVICE pointers unless marked host.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *
+ *   gsr_forward / gsr_backward
+ *       the `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` calls made by the external CUDA
+ *       extension `diff_gaussian_rasterization`, which the reference imports at gaussian_renderer/__init__.py:14
+ *       and invokes at gaussian_renderer/__init__.py:51-62 (GaussianRasterizer.forward) and, through autograd,
+ *       from train_stage2.py:83 (backward).  Argument meaning follows that call: precomputed colours, no SH.
+ *   cs_forward / cs_backward
+ *       `corr_sampler.forward` / `corr_sampler.backward` of the external RAFT-Stereo sampler extension, called at
+ *       core/corr.py:22 and core/corr.py:28.
+ *   gsr_pack_views
+ *       the per-sample flatten + boolean-mask gather + concat + rgb affine of lib/GaussianRender.py:15-34.
+ *   zsplat_forward
+ *       the Taichi kernel TaichiRenderBatch.render_respective_color, lib/TaichiRender.py:13-24.
+ */
+#ifndef GPSGS_H
+#define GPSGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPSGS_ABI_VERSION 1
+
+enum {
+    GPSGS_OK = 0,
+    GPSGS_E_INVALID = -1,    /* bad argument (NULL pointer, negative size, unsupported dtype) */
+    GPSGS_E_WORKSPACE = -2,  /* workspace_bytes smaller than gsr_workspace_bytes() for these dimensions */
+    GPSGS_E_LAUNCH = -3,     /* a HIP launch failed (hipGetLastError != hipSuccess) */
+    GPSGS_E_NO_DEVICE = -4   /* no HIP device */
+};
+
+/* flags for gsr_forward / gsr_backward */
+#define GSR_FLAG_DEBUG 1u /* synchronise and check after every kernel (the reference hard-codes debug=False) */
+
+int gpsgs_abi_version(void);
+const char *gpsgs_build_info(void); /* "gfx950 <compiler> <date>" */
+
+/* ---- rasteriser ---------------------------------------------------------------------------------------------
+ * Workspace: one caller-owned device buffer (>= gsr_workspace_bytes, 256-byte aligned) that carries the forward's
+ * state to the backward (what upstream keeps in geomBuffer / binningBuffer / imgBuffer).
+ * `instance_capacity` bounds R = number of (Gaussian, tile) instances the buffer can bin.  R is data dependent; the
+ * forward never reads it back.  Instead the header records the R that was needed and an overflow flag:
+ *   - overflow == 0: results are exact;
+ *   - overflow != 0: NOTHING was rendered (out_color untouched apart from zero fill); the caller must re-run with
+ *     instance_capacity >= the reported R.  (Upstream sizes the buffer with a blocking D2H read of R on every call.)
+ */
+typedef struct GsrHeader {      /* first bytes of the workspace, device memory */
+    uint64_t num_rendered;      /* R needed by the last gsr_forward */
+    uint32_t overflow;          /* 1 if R > instance_capacity */
+    uint32_t max_tile_count;    /* longest per-tile list */
+    uint32_t num_visible;       /* Gaussians with radius > 0 */
+    uint32_t reserved[11];
+} GsrHeader;
+
+size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity);
+
+/* Forward.  Inputs fp32, contiguous: means3D[P,3], colors[P,3], opacities[P], scales[P,3], rotations[P,4] (w,x,y,z;
+ * NOT re-normalised), viewmatrix[16], projmatrix[16] (flat column-major = the transposed tensors the reference
+ * passes), bg[3].  Outputs: out_color[3,H,W], radii[P].  P == 0: out_color is zero-filled (not background). */
+int gsr_forward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream);
+
+/* Backward.  Same inputs and the workspace left by the matching gsr_forward, plus dL_dpix[3,H,W] (contiguous).
+ * Writes (does not accumulate) dL_dmeans3D[P,3], dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P],
+ * dL_dscales[P,3], dL_drotations[P,4]. */
+int gsr_backward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                 const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                 const float *viewmatrix, const float *projmatrix, const float *bg, const int *radii,
+                 const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors,
+                 float *dL_dopacity, float *dL_dscales, float *dL_drotations, void *workspace,
+                 size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream);
+
+/* Blocking helper for non-torch hosts: copies the header to host memory and synchronises `stream`. */
+int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream);
+
+/* Debug/parity helper: copies selected intermediate arrays out of the workspace into caller DEVICE buffers (any may
+ * be NULL): depth[P], xy[P,2], conic_opacity[P,4], rect[P,4] (int32 minx,miny,maxx,maxy), tile_ranges[T,2] (int64),
+ * point_list[num_rendered] (uint32, sorted), final_T[H,W], n_contrib[H,W]. */
+int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, float *depth,
+                     float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges, uint32_t *point_list,
+                     float *final_T, uint32_t *n_contrib, void *stream);
+
+/* ---- 1-D correlation sampler ----------------------------------------------------------------------------------
+ * volume[N,H1,W1,W2], coords[N,H1,W1] fp32 (channel 0 of the reference's [N,1,H1,W1]), out[N,2r+1,H1,W1].
+ * dtype: 0 = fp32, 1 = fp16 (volume / out / grads; coords always fp32). */
+int cs_forward(const void *volume, const float *coords, void *out, int N, int H1, int W1, int W2, int radius,
+               int dtype, void *stream);
+int cs_backward(const float *coords, const void *grad_out, void *grad_volume, int N, int H1, int W1, int W2,
+                int radius, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSGS_H */

@@ -74,8 +74,10 @@ class OracleRasterizer:
         return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
     def forward(self, means3D, colors, opacities, scales, rotations, view, proj, W, H, tanfovx, tanfovy, bg,
-                scale_modifier=1.0):
+                scale_modifier=1.0, decisions=None):
         """view/proj: the [4,4] tensors exactly as the reference hands them over (transposed; flat = column-major).
+        decisions: optional geom() dict of ANOTHER evaluation (normally the fp32 oracle) whose discrete decisions
+        (radii/visibility, tile rect, fp32 depth sort key) are adopted; see gsr_oracle.c.
         Returns (color[3,H,W], radii[P])."""
         P = int(np.asarray(means3D).reshape(-1, 3).shape[0])
         a = dict(
@@ -86,11 +88,16 @@ class OracleRasterizer:
         self.args = (P, a, float(scale_modifier), int(W), int(H), float(tanfovx), float(tanfovy))
         out = np.zeros((3, H, W), self.np)
         radii = np.zeros((max(P, 1),), np.int32)
+        ov = (None, None, None)
+        if decisions is not None and P > 0:
+            ov = (np.ascontiguousarray(decisions["radii"], np.int32), np.ascontiguousarray(decisions["rect"], np.int32),
+                  np.ascontiguousarray(decisions["depth"], np.float32))
+        self._ov = ov
         rc = self._f("forward")(
             self.h, C.c_int(P), self._p(a["means3D"]), self._p(a["colors"]), self._p(a["opacities"]),
             self._p(a["scales"]), self._p(a["rotations"]), self.ct(scale_modifier), self._p(a["view"]),
             self._p(a["proj"]), C.c_int(W), C.c_int(H), self.ct(tanfovx), self.ct(tanfovy), self._p(a["bg"]),
-            self._p(out), self._p(radii))
+            self._p(out), self._p(radii), self._p(ov[0]), self._p(ov[1]), self._p(ov[2]))
         if rc != 0:
             raise RuntimeError("oracle forward failed rc=%d" % rc)
         return out, radii[:P]
