@@ -1,0 +1,211 @@
+"""bench.py -- the hot-path benchmark the driver runs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Metric (BASELINE.json): novel views/s at 1024x1024 with ~600k pixel-Gaussians.  One "step" = one pass of the render
+hot path over one synthetic view of BASELINE config 2: HIP rasteriser forward + backward (1024x1024, P = 600,000
+Gaussians resident in HBM before the timed region).  Forward-only throughput is reported next to it.
+N > 1: every rank renders its own views (independent units, no data-path collective) -> weak scaling; the only
+collectives are the timing barrier and the MAX-over-ranks reduction of the elapsed time.
+
+The printed JSON line also carries
+  roofline     : the dominant kernel (backward compositing) priced against the HBM roofline with ALGORITHMIC bytes
+                 (DESIGN.md "Kernels and rooflines"); its duration is measured live with hipEvents on the launch stream;
+  cpu_baseline : the fp32 CPU oracle ("port": the reference's rasteriser is an external CUDA extension that cannot be
+                 built here) on the host cores, rank 0 at N=1 only, on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+VALU_PEAK_TLANEOPS = 78.6   # 157.3 TFLOP/s fp32 vector = 78.6 T FMA lane-ops/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--res", type=int, default=1024, help="source resolution (config 2: 1024)")
+    ap.add_argument("--render-res", type=int, default=None, help="render resolution (default = --res)")
+    ap.add_argument("--gaussians", type=int, default=600_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import gps_gaussian_amd  # noqa: F401
+    from gps_gaussian_amd import _capi, synthetic as S
+    from gps_gaussian_amd import rasterizer as RZ
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    _capi.lib()  # fail loudly if the HIP library is missing
+
+    # ---- synthetic workload: one stereo pair per rank (different pose per rank), resident in HBM ------------------
+    render_res = args.render_res or args.res
+    s = S.make_stereo_sample(args.res, args.gaussians, seed=S.SEED + rank, render_res=render_res)
+    g = S.compact_sample(s)
+    cam = s["novel_view"]
+    P = g["means3D"].shape[0]
+    H = W = render_res
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    t = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in names}
+    m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+    rs = RZ.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(float(cam["FovX"]) * 0.5), tanfovy=math.tan(float(cam["FovY"]) * 0.5),
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=torch.from_numpy(cam["world_view_transform"]).to(dev),
+        projmatrix=torch.from_numpy(cam["full_proj_transform"]).to(dev), sh_degree=3,
+        campos=torch.from_numpy(cam["camera_center"]).to(dev), prefiltered=False, debug=False)
+    rast = RZ.GaussianRasterizer(rs)
+    gout = torch.randn(3, H, W, device=dev)  # dL/dpix of a synthetic loss, random (not zero: DVFS note in the guide)
+
+    def fwd_bwd():
+        for v in t.values():
+            v.grad = None
+        m2.grad = None
+        img, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=None, colors_precomp=t["colors"],
+                      scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        img.backward(gout)
+
+    def fwd_only():
+        with torch.no_grad():
+            rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=None, colors_precomp=t["colors"],
+                 scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if world > 1:
+            x = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            el = float(x.item())
+        return el
+
+    # ---- the timed region: EXACTLY --steps fwd+bwd steps, hipEvents bracketing every kernel on the launch stream ----
+    RZ.set_stage_timing(True)
+    for _ in range(args.warmup):
+        fwd_bwd()
+    torch.cuda.synchronize(dev)
+    _capi.timing_read()  # drop the warm-up records
+    elapsed = timed(fwd_bwd, args.steps, 0)
+    stages = _capi.timing_read()
+    RZ.set_stage_timing(False)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+    R = int(RZ.last_stats(dev).get("last_R", 0))  # measured number of (Gaussian, tile) instances of this view
+
+    # secondary numbers (outside the headline region): forward-only, and the non-blocking check mode
+    el_fwd = timed(fwd_only, args.steps, 3)
+    os.environ["GPSGS_CHECK"] = "deferred"
+    el_def = timed(fwd_bwd, args.steps, 3)
+    el_fwd_def = timed(fwd_only, args.steps, 3)
+    os.environ["GPSGS_CHECK"] = "sync"
+    torch.cuda.synchronize(dev)
+
+    # ---- roofline of the dominant kernel -------------------------------------------------------------------------------
+    T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    npix = W * H
+    alg_bytes = {  # ALGORITHMIC bytes per launch: each input read once, each output written once
+        "preprocess": 44 * P + 48 * P + 4 * P,
+        "scan": 8 * T_tiles,
+        "scatter": 16 * P + 8 * R,
+        "sort": 8 * R + 4 * R + 8 * T_tiles,
+        "composite_fwd": 40 * R + 8 * T_tiles + 12 * npix + 8 * npix,
+        "composite_bwd": 40 * R + 8 * T_tiles + 20 * npix + 44 * P,
+        "preprocess_bwd": 48 * P + 44 * P + 68 * P,
+    }
+    per_stage = {}
+    for name, (ms, n) in stages.items():
+        if n:
+            avg_ms = ms / n
+            per_stage[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
+                               "hbm_gbs": round(alg_bytes[name] / (avg_ms * 1e-3) / 1e9, 1)}
+    dom = max(per_stage, key=lambda k: per_stage[k]["avg_us"]) if per_stage else None
+    roofline = None
+    if dom:
+        achieved = per_stage[dom]["hbm_gbs"]
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # filled from the rocprofv3 --pmc passes (per launch)
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": per_stage[dom]["avg_us"],
+                    # compositing is FP32-VALU/LDS bound, not HBM bound: lane-op roofline of the same kernel
+                    "valu_lane_ops_per_launch": 256 * R * (60 if dom == "composite_bwd" else 30),
+                    "valu_frac": round(256 * R * (60 if dom == "composite_bwd" else 30) / (per_stage[dom]["avg_us"] * 1e-6)
+                                       / (VALU_PEAK_TLANEOPS * 1e12), 4)}
+
+    # ---- CPU baseline: the fp32 oracle on the host cores (rank 0, N=1 only), bounded sample ------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.gsr_oracle import OracleRasterizer
+        o = OracleRasterizer("f32")
+        dp = gout.cpu().numpy()
+        fa = (g["means3D"], g["colors"], g["opacities"], g["scales"], g["rotations"], cam["world_view_transform"],
+              cam["full_proj_transform"], W, H, rs.tanfovx, rs.tanfovy, np.zeros(3, np.float32))
+        o.forward(*fa); o.backward(dp)  # warm-up (page in, OpenMP pool)
+        n_cpu, t0 = 0, time.perf_counter()
+        while n_cpu < 3 or (time.perf_counter() - t0 < 4.0 and n_cpu < 20):
+            o.forward(*fa); o.backward(dp); n_cpu += 1
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(n_cpu / dt, 3), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": "%d fwd+bwd views of the same %dx%d / %d-Gaussian workload, oracle/gsr_oracle.c fp32 + OpenMP" % (n_cpu, W, H, P)}
+
+    if rank == 0:
+        line = {
+            "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward", "value": round(value, 2),
+            "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d instances, "
+                                   "HIP rasteriser forward+backward, one view per step per GPU" % (W, H, P, R),
+                       "check_mode": "sync (exact; 64-byte header read back at the end of every forward)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "forward_only_views_per_s": round(world * args.steps / el_fwd, 2),
+            "deferred_check_views_per_s": {"fwd_bwd": round(world * args.steps / el_def, 2), "fwd": round(world * args.steps / el_fwd_def, 2)},
+            "stages": per_stage,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,12 +8,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_forward", "gsr_backward", "gsr_read_header",
-    "gsr_export_state", "cs_forward", "cs_backward",
+    "gsr_export_state", "gsr_timing_read", "cs_forward", "cs_backward",
 )
 
 GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
 _ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "no HIP device"}
 GSR_FLAG_DEBUG = 1
+GSR_FLAG_TIMING = 2
+STAGES = ("preprocess", "scan", "scatter", "sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 
 
 class GsrHeader(C.Structure):
@@ -50,6 +52,8 @@ def lib():
     l.gsr_read_header.argtypes = [vp, C.POINTER(GsrHeader), vp]
     l.gsr_export_state.restype = i32
     l.gsr_export_state.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    l.gsr_timing_read.restype = i32
+    l.gsr_timing_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     l.cs_forward.restype = i32
     l.cs_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     l.cs_backward.restype = i32
@@ -63,3 +67,11 @@ def lib():
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("gps_gaussian_amd: %s failed: %s (%d)" % (what, _ERR.get(rc, "unknown"), rc))
+
+
+def timing_read():
+    """Per-stage {name: (total_ms, launches)} of the calls made with GSR_FLAG_TIMING since the last read."""
+    ms = (C.c_float * len(STAGES))()
+    n = (C.c_int * len(STAGES))()
+    check(lib().gsr_timing_read(ms, n), "gsr_timing_read")
+    return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(STAGES)}

@@ -17,6 +17,34 @@ inline int check(hipStream_t s, unsigned flags) {
     return GPSGS_OK;
 }
 
+// ---- optional per-stage hipEvent recorder (GSR_FLAG_TIMING) ---------------------------------------------------------
+constexpr int TIMING_MAX = 8192;
+struct Recorder {
+    hipEvent_t ev[TIMING_MAX][2];
+    int stage[TIMING_MAX];
+    int created = 0, n = 0;
+} g_rec;
+
+struct StageTimer {  // RAII: records an event pair around one stage when timing is on
+    bool on;
+    int slot;
+    hipStream_t s;
+    StageTimer(unsigned flags, int stage, hipStream_t s_) : on((flags & GSR_FLAG_TIMING) != 0), slot(-1), s(s_) {
+        if (!on || g_rec.n >= TIMING_MAX) { on = false; return; }
+        slot = g_rec.n++;
+        if (slot >= g_rec.created) {
+            (void)hipEventCreate(&g_rec.ev[slot][0]);
+            (void)hipEventCreate(&g_rec.ev[slot][1]);
+            g_rec.created = slot + 1;
+        }
+        g_rec.stage[slot] = stage;
+        (void)hipEventRecord(g_rec.ev[slot][0], s);
+    }
+    ~StageTimer() {
+        if (on) (void)hipEventRecord(g_rec.ev[slot][1], s);
+    }
+};
+
 __global__ void k_export(int P, int T, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ tile_offset, float *depth,
                          float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -81,15 +109,30 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity;
 
     int rc;
-    gsr_launch_preprocess(q, splats, tile_count, hdr, s);
+    {
+        StageTimer t(flags, GSR_STAGE_PREPROCESS, s);
+        gsr_launch_preprocess(q, splats, tile_count, hdr, s);
+    }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-    gsr_launch_scan(tile_count, tile_offset, tile_cursor, L.T, instance_capacity, hdr, s);
+    {
+        StageTimer t(flags, GSR_STAGE_SCAN, s);
+        gsr_launch_scan(tile_count, tile_offset, tile_cursor, L.T, instance_capacity, hdr, s);
+    }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-    gsr_launch_scatter(P, L.gx, splats, tile_cursor, keys, instance_capacity, hdr, s);
+    {
+        StageTimer t(flags, GSR_STAGE_SCATTER, s);
+        gsr_launch_scatter(P, L.gx, splats, tile_cursor, keys, instance_capacity, hdr, s);
+    }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-    gsr_launch_sort(L.T, tile_offset, keys, point_list, hdr, s);
+    {
+        StageTimer t(flags, GSR_STAGE_SORT, s);
+        gsr_launch_sort(L.T, tile_offset, keys, point_list, hdr, s);
+    }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-    gsr_launch_composite_fwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+    {
+        StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
+        gsr_launch_composite_fwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+    }
     return check(s, flags);
 }
 
@@ -118,7 +161,10 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
 
     if (hipMemsetAsync(gacc, 0, (size_t)P * sizeof(GsrGradAcc), s) != hipSuccess) return GPSGS_E_LAUNCH;
     int rc;
-    gsr_launch_composite_bwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, dL_dpix, final_T, n_contrib, gacc, hdr, s);
+    {
+        StageTimer t(flags, GSR_STAGE_COMPOSITE_BWD, s);
+        gsr_launch_composite_bwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, dL_dpix, final_T, n_contrib, gacc, hdr, s);
+    }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     GsrBwdParams b;
     b.P = P; b.W = width; b.H = height;
@@ -127,8 +173,25 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     b.view = viewmatrix; b.proj = projmatrix; b.radii = radii;
     b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
-    gsr_launch_preprocess_bwd(b, gacc, s);
+    {
+        StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);
+        gsr_launch_preprocess_bwd(b, gacc, s);
+    }
     return check(s, flags);
+}
+
+extern "C" int gsr_timing_read(float *ms_sum_host, int *launches_host) {
+    if (!ms_sum_host || !launches_host) return GPSGS_E_INVALID;
+    for (int i = 0; i < GSR_STAGE_COUNT; i++) { ms_sum_host[i] = 0.f; launches_host[i] = 0; }
+    if (hipDeviceSynchronize() != hipSuccess) return GPSGS_E_LAUNCH;
+    for (int i = 0; i < g_rec.n; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_rec.ev[i][0], g_rec.ev[i][1]) != hipSuccess) continue;
+        ms_sum_host[g_rec.stage[i]] += ms;
+        launches_host[g_rec.stage[i]] += 1;
+    }
+    g_rec.n = 0;
+    return GPSGS_OK;
 }
 
 extern "C" int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream) {

@@ -42,6 +42,15 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+_extra_flags = 0  # bench.py sets GSR_FLAG_TIMING here to bracket every kernel with hipEvents
+
+
+def set_stage_timing(on):
+    """Turn per-stage hipEvent recording on/off for subsequent calls (read with _capi.timing_read())."""
+    global _extra_flags
+    _extra_flags = _capi.GSR_FLAG_TIMING if on else 0
+
+
 # ---- capacity policy --------------------------------------------------------------------------------------------
 _MIN_CAP = 1 << 16
 _state = {}  # device index -> dict(ratio=instances per Gaussian seen so far, pending=[(event, pinned_header, P)])
@@ -85,6 +94,7 @@ def _drain_pending(st, block=False):
 
 
 def _learn(st, R, P):
+    st["last_R"] = R
     if P > 0:
         st["ratio"] = max(st["ratio"], R / P)
     st["floor"] = max(st["floor"], min(int(R * 1.25) + 4096, 0x7fffffff))
@@ -140,7 +150,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         view = _cam(rs.viewmatrix, 16, dev)
         proj = _cam(rs.projmatrix, 16, dev)
         bg = _cam(rs.bg, 3, dev)
-        flags = _capi.GSR_FLAG_DEBUG if rs.debug else 0
+        flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags
         mode = _check_mode()
         st = _dev_state(dev)
         with torch.cuda.device(dev):
@@ -200,7 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                       float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
                                       _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
-                                      ws.numel(), ctx.cap, _capi.GSR_FLAG_DEBUG if rs.debug else 0, stream)
+                                      ws.numel(), ctx.cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags, stream)
                 _capi.check(rc, "gsr_backward")
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
         return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None

@@ -42,7 +42,14 @@ enum {
 };
 
 /* flags for gsr_forward / gsr_backward */
-#define GSR_FLAG_DEBUG 1u /* synchronise and check after every kernel (the reference hard-codes debug=False) */
+#define GSR_FLAG_DEBUG 1u  /* synchronise and check after every kernel (the reference hard-codes debug=False) */
+#define GSR_FLAG_TIMING 2u /* bracket every stage with hipEvents on `stream`; read them with gsr_timing_read() */
+
+/* stage ids reported by gsr_timing_read() */
+enum {
+    GSR_STAGE_PREPROCESS = 0, GSR_STAGE_SCAN, GSR_STAGE_SCATTER, GSR_STAGE_SORT, GSR_STAGE_COMPOSITE_FWD,
+    GSR_STAGE_COMPOSITE_BWD, GSR_STAGE_PREPROCESS_BWD, GSR_STAGE_COUNT
+};
 
 int gpsgs_abi_version(void);
 const char *gpsgs_build_info(void); /* "gfx950 <compiler> <date>" */
@@ -86,6 +93,11 @@ int gsr_backward(int P, int width, int height, const float *means3D, const float
 
 /* Blocking helper for non-torch hosts: copies the header to host memory and synchronises `stream`. */
 int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream);
+
+/* Profiling helper (not thread safe, not for use under graph capture): synchronises, then adds up the hipEvent
+ * durations recorded by calls that carried GSR_FLAG_TIMING since the last read.  ms_sum[GSR_STAGE_COUNT] receives the
+ * total milliseconds per stage, launches[GSR_STAGE_COUNT] the number of timed launches.  Resets the recorder. */
+int gsr_timing_read(float *ms_sum_host, int *launches_host);
 
 /* Debug/parity helper: copies selected intermediate arrays out of the workspace into caller DEVICE buffers (any may
  * be NULL): depth[P], xy[P,2], conic_opacity[P,4], rect[P,4] (int32 minx,miny,maxx,maxy), tile_ranges[T,2] (int64),

@@ -1,0 +1,116 @@
+"""Generates the golden fixtures in this directory by IMPORTING the reference (read-only at /root/reference).
+
+Run here (the build container) only:   python tests/golden/make_golden.py
+/root/reference does not exist on the GPU box; tests read the committed .npz files, never the reference.
+
+Fixtures (all produced by the reference's own code, on CPU):
+  camera_golden.npz        lib/utils.py::get_novel_calib (+ lib/graphics_utils.py) on the synthetic rig, 3 ratios x {hr, not hr}
+  depth2pc_golden.npz      lib/utils.py::depth2pc on a small random inverse-depth map
+  corr_sampler_golden.npz  core/corr.py::CorrBlock1D lookups (4 levels, radius 4) + autograd gradient w.r.t. each volume
+  pts2render_golden.npz    lib/GaussianRender.py::pts2render's compaction: the exact arguments it hands to render()
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+torch.manual_seed(1314)
+np.random.seed(1314)
+torch.Tensor.cuda = lambda self, *a, **k: self  # the reference hard-codes .cuda(); there is no GPU here
+
+import gps_gaussian_amd  # noqa: E402
+from gps_gaussian_amd import synthetic as S  # noqa: E402
+
+# ---- camera -------------------------------------------------------------------------------------------------------
+from lib.utils import get_novel_calib, depth2pc  # noqa: E402
+
+res = 1024
+(i0, e0), (i1, e1) = S.source_camera(res, 0.0), S.source_camera(res, 22.5)
+cam = {}
+for hr in (False, True):
+    for ratio in (0.1, 0.5, 0.9):
+        side = res * 2 if hr else res
+        data = {"lmain": {"intr": torch.from_numpy(i0)[None], "extr": torch.from_numpy(e0)[None]},
+                "rmain": {"intr": torch.from_numpy(i1)[None], "extr": torch.from_numpy(e1)[None]},
+                "novel_view": {"width": torch.tensor([side]), "height": torch.tensor([side])}}
+        opt = SimpleNamespace(use_hr_img=hr, znear=0.01, zfar=100.0, trans=[0.0, 0.0, 0.0], scale=1.0)
+        out = get_novel_calib(data, opt, ratio=ratio)["novel_view"]
+        tag = "hr%d_r%02d_" % (int(hr), int(ratio * 10))
+        for k in ("FovX", "FovY", "world_view_transform", "full_proj_transform", "camera_center"):
+            cam[tag + k] = out[k][0].numpy()
+cam.update(intr0=i0, extr0=e0, intr1=i1, extr1=e1)
+np.savez_compressed(os.path.join(HERE, "camera_golden.npz"), **cam)
+
+# ---- depth2pc -----------------------------------------------------------------------------------------------------
+rng = np.random.default_rng(7)
+S_ = 24
+inv = rng.uniform(0.3, 0.7, (1, 1, S_, S_)).astype(np.float32)
+inv[0, 0, :3] = 0.0
+k_small = i0.copy(); k_small[:2] *= S_ / res
+pts = depth2pc(torch.from_numpy(inv), torch.from_numpy(e0)[None], torch.from_numpy(k_small)[None])
+np.savez_compressed(os.path.join(HERE, "depth2pc_golden.npz"), inv_depth=inv[0, 0], intr=k_small, extr=e0, xyz=pts[0].numpy())
+
+# ---- corr sampler -------------------------------------------------------------------------------------------------
+from core.corr import CorrBlock1D  # noqa: E402
+
+B, D, H, W1 = 2, 16, 5, 40
+f1 = torch.randn(B, D, H, W1)
+f2 = torch.randn(B, D, H, W1)
+blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+vols = [v.detach().clone().requires_grad_(True) for v in blk.corr_pyramid[:4]]
+blk.corr_pyramid = vols + blk.corr_pyramid[4:]
+coords = torch.rand(B, 2, H, W1) * (W1 + 12) - 6.0       # includes taps left and right of the volume
+coords[0, 0, 0, :4] = torch.tensor([0.0, 3.0, float(W1 - 1), -4.0])  # exact integers / borders
+out = blk(coords)                                          # [B, 4*9, H, W1]
+gout = torch.randn_like(out)
+out.backward(gout)
+cs = {"coords": coords[:, :1].numpy(), "out": out.detach().numpy(), "grad_out": gout.numpy(), "radius": np.int32(4)}
+for lvl, v in enumerate(vols):
+    cs["volume%d" % lvl] = v.detach().reshape(B, H, W1, -1).numpy()       # the layout corr_sampler.forward receives
+    cs["grad_volume%d" % lvl] = v.grad.reshape(B, H, W1, -1).numpy()
+np.savez_compressed(os.path.join(HERE, "corr_sampler_golden.npz"), **cs)
+
+# ---- pts2render compaction ----------------------------------------------------------------------------------------
+stub = types.ModuleType("diff_gaussian_rasterization")
+stub.GaussianRasterizationSettings = object
+stub.GaussianRasterizer = object
+sys.modules["diff_gaussian_rasterization"] = stub
+import lib.GaussianRender as GR  # noqa: E402
+
+captured = []
+
+
+def fake_render(data, idx, xyz, rgb, rot, scale, opacity, bg_color):
+    captured.append(dict(xyz=xyz.numpy().copy(), rgb=rgb.numpy().copy(), rot=rot.numpy().copy(), scale=scale.numpy().copy(),
+                         opacity=opacity.numpy().copy()))
+    return torch.zeros(3, 4, 4)
+
+
+GR.render = fake_render
+Bp, Sp = 2, 12
+data = {}
+g = torch.Generator().manual_seed(5)
+for view in ("lmain", "rmain"):
+    data[view] = dict(img=torch.rand(Bp, 3, Sp, Sp, generator=g) * 2 - 1, xyz=torch.randn(Bp, Sp * Sp, 3, generator=g),
+                      pts_valid=torch.rand(Bp, Sp * Sp, generator=g) > 0.4, rot_maps=torch.randn(Bp, 4, Sp, Sp, generator=g),
+                      scale_maps=torch.rand(Bp, 3, Sp, Sp, generator=g) * 0.01, opacity_maps=torch.rand(Bp, 1, Sp, Sp, generator=g))
+data["novel_view"] = {}
+GR.pts2render(data, [0, 0, 0])
+pk = {}
+for view in ("lmain", "rmain"):
+    for k, v in data[view].items():
+        pk["%s_%s" % (view, k)] = v.numpy()
+for i, c in enumerate(captured):
+    for k, v in c.items():
+        pk["out%d_%s" % (i, k)] = v
+np.savez_compressed(os.path.join(HERE, "pts2render_golden.npz"), **pk)
+print("golden fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

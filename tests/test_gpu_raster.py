@@ -1,0 +1,280 @@
+"""GPU (-m gpu): the HIP rasteriser, called through the drop-in module and the C-ABI, against the CPU oracle.
+
+Tolerances (BASELINE.json north_star): RGB <= 1e-4, gradients <= 1e-3.  The algorithm has discontinuous branches
+(alpha < 1/255 skip, T < 1e-4 stop): a pixel sitting on a threshold may legitimately take the other branch under a
+1-ulp difference in exp().  The oracle reports such pixels (fragility map); they are required to be rare and their
+error bounded by one dropped/added contribution, everything else must meet the tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import kat_cases
+from conftest import GOLDEN, hip_render, oracle_render, touched_by_fragile
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+def _hip_kat_render(scene):
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    P = scene["means3D"].shape[0]
+    if P == 0:
+        img, radii, _, _ = hip_render(scene)
+        return img, radii, None
+    img, radii, _, t = hip_render(scene, np.zeros((3, scene["H"], scene["W"]), np.float32))
+    st = RZ.export_state(t["ws"], P, scene["W"], scene["H"], t["cap"])
+    return img, radii, dict(n_contrib=st["n_contrib"].cpu().numpy(), final_T=st["final_T"].cpu().numpy())
+
+
+@pytest.mark.parametrize("case", kat_cases.ALL, ids=lambda c: c.__name__)
+def test_known_answers_on_gpu(case):
+    case(_hip_kat_render, 2e-6)
+
+
+def _scenes():
+    import gps_gaussian_amd  # noqa: F401
+    from gps_gaussian_amd import synthetic as S
+    return {
+        "c1_256_30k": lambda: S.make_scene(256, 30000),
+        "cloud_333x277_20k": lambda: S.make_uniform_cloud(20000, 333, 277, seed=3, scale_med=0.02),
+        "cloud_big_splats_96x80": lambda: S.make_uniform_cloud(3000, 96, 80, seed=5, scale_med=0.08),
+        "hr_512_from_256": lambda: S.make_scene(256, 30000, render_res=512),
+    }
+
+
+def _norm_err(a, ref):
+    s = np.abs(ref).max() + 1e-30
+    return np.abs(a - ref) / (np.abs(ref) + GRAD_TOL * s)
+
+
+@pytest.mark.parametrize("name", ["c1_256_30k", "cloud_333x277_20k", "cloud_big_splats_96x80", "hr_512_from_256"])
+def test_forward_backward_parity(name):
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    g = _scenes()[name]()
+    H, W, P = g["H"], g["W"], g["means3D"].shape[0]
+    dpix = np.random.default_rng(11).standard_normal((3, H, W)).astype(np.float32)
+    img, radii, grads, t = hip_render(g, dpix)
+    o, oimg, oradii = oracle_render(g, "f32")
+
+    # --- discrete decisions and per-Gaussian geometry: bit-exact (preprocess is compiled without FMA contraction)
+    np.testing.assert_array_equal(radii, oradii)
+    st = RZ.export_state(t["ws"], P, W, H, t["cap"])
+    geom, binning = o.geom(), o.binning()
+    vis = oradii > 0
+    assert st["overflow"] == 0 and st["num_rendered"] == o.num_rendered
+    np.testing.assert_array_equal(st["rect"].cpu().numpy()[vis], geom["rect"][vis])
+    np.testing.assert_array_equal(st["depth"].cpu().numpy()[vis], geom["depth"][vis])
+    np.testing.assert_array_equal(st["xy"].cpu().numpy()[vis], geom["xy"][vis])
+    np.testing.assert_array_equal(st["conic_opacity"].cpu().numpy()[vis], geom["conic_opacity"][vis])
+    np.testing.assert_array_equal(st["ranges"].cpu().numpy(), binning["ranges"])
+    # --- per-tile depth order: identical to the stable (depth, index) order
+    np.testing.assert_array_equal(st["point_list"].cpu().numpy().astype(np.uint32), binning["point_list"])
+
+    # --- image
+    solid, touched = touched_by_fragile(o)
+    err = np.abs(img - oimg).max(0)
+    assert solid.mean() > 0.995
+    assert err[solid].max() <= RGB_TOL, "max err %.3e" % err[solid].max()
+    assert err.max() <= 2.0 / 255 + 1e-3          # a flipped branch changes a pixel by at most one ~1/255 contribution
+    assert (err > RGB_TOL).sum() <= max(2, int(1e-4 * err.size))
+    nc = st["n_contrib"].cpu().numpy().astype(np.uint32)
+    assert (nc != binning["n_contrib"])[solid].sum() == 0
+    np.testing.assert_allclose(st["final_T"].cpu().numpy()[solid], binning["final_T"][solid], rtol=1e-4, atol=1e-7)
+
+    # --- gradients vs the fp32 oracle (same decisions): every Gaussian not touching a fragile pixel within 1e-3
+    og = o.backward(dpix)
+    assert touched.mean() < 0.35
+    for k in grads:
+        e = _norm_err(grads[k], og[k])
+        assert e[~touched].max() <= GRAD_TOL, "%s: %.3e" % (k, e[~touched].max())
+        assert (e > GRAD_TOL).any(axis=-1).mean() < 2e-3, k
+        assert np.abs(og[k]).max() > 0, k
+    # invisible Gaussians receive exactly zero gradient
+    for k in grads:
+        assert np.abs(grads[k][~vis]).max(initial=0.0) == 0.0
+
+    # --- gradients vs the fp64 oracle evaluated with the same discrete decisions (gradient truth): fp32-level agreement
+    o64, _, _ = oracle_render(g, "f64", decisions=geom)
+    og64 = o64.backward(dpix)
+    for k in grads:
+        e = _norm_err(grads[k], og64[k])
+        assert np.quantile(e, 0.99) <= GRAD_TOL, "%s q99 %.3e" % (k, np.quantile(e, 0.99))
+        assert np.abs(grads[k] - og64[k]).max() <= 0.05 * np.abs(og64[k]).max(), k
+
+
+def test_config2_full_size_vs_oracle_and_properties():
+    """BASELINE config 2: 1024^2, 600k Gaussians.  Oracle comparison (the fp32 oracle needs ~0.2 s) + size-independent properties."""
+    import torch
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_scene(1024, 600000)
+    H, W = g["H"], g["W"]
+    rng = np.random.default_rng(3)
+    dpix = rng.standard_normal((3, H, W)).astype(np.float32)
+    img, radii, grads, _ = hip_render(g, dpix)
+    o, oimg, oradii = oracle_render(g, "f32")
+    np.testing.assert_array_equal(radii, oradii)
+    solid, touched = touched_by_fragile(o)
+    err = np.abs(img - oimg).max(0)
+    assert err[solid].max() <= RGB_TOL and (err > RGB_TOL).sum() <= 100 and solid.mean() > 0.998
+    og = o.backward(dpix)
+    for k in grads:
+        e = _norm_err(grads[k], og[k])
+        assert e[~touched].max() <= GRAD_TOL, "%s %.3e" % (k, e[~touched].max())
+        assert (e > GRAD_TOL).any(axis=-1).mean() < 1e-4, k
+
+    # determinism of the forward (sort is on unique 64-bit keys, compositing order fixed): bit-identical re-run
+    img2, _, _, _ = hip_render(g)
+    np.testing.assert_array_equal(img, img2)
+    # colour linearity with a black background: render(2c) == 2 render(c) exactly (power-of-two scaling is exact in fp32)
+    g2 = dict(g); g2["colors"] = g["colors"] * 2
+    img3, _, _, _ = hip_render(g2)
+    np.testing.assert_array_equal(img3, 2 * img)
+    # backward is linear in dL/dpix: grads(2 d) == 2 grads(d) up to the atomic summation order
+    _, _, grads2, _ = hip_render(g, 2 * dpix)
+    for k in grads:
+        s = np.abs(grads[k]).max()
+        assert np.abs(grads2[k] - 2 * grads[k]).max() <= 2e-4 * s, k
+    # appending fully transparent Gaussians changes nothing
+    n_extra = 1000
+    g4 = {k: (np.concatenate([v, v[:n_extra]], 0) if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[0] == 600000 else v) for k, v in g.items()}
+    g4["opacities"] = g4["opacities"].copy(); g4["opacities"][-n_extra:] = 0
+    img5, _, _, _ = hip_render(g4)
+    np.testing.assert_array_equal(img5, img)
+
+
+@pytest.mark.parametrize("n,expect_path", [(1500, "lds_small"), (9000, "lds_large"), (40000, "global")])
+def test_every_sort_path(n, expect_path):
+    """Tiny image, many large splats: per-tile lists of ~n (<=2048: 16 KiB LDS kernel; <=16384: 128 KiB LDS kernel; beyond: global)."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_uniform_cloud(n, 32, 32, seed=21, scale_med=0.2, z_range=(1.0, 6.0), behind_frac=0.0)
+    g["opacities"] = (g["opacities"] * 0.05).astype(np.float32)   # keep T high so every tile list is walked deep
+    dpix = np.ones((3, 32, 32), np.float32)
+    img, radii, grads, t = hip_render(g, dpix)
+    o, oimg, oradii = oracle_render(g, "f32")
+    st = RZ.export_state(t["ws"], n, 32, 32, t["cap"])
+    longest = int((o.binning()["ranges"][:, 1] - o.binning()["ranges"][:, 0]).max())
+    assert {"lds_small": longest <= 2048, "lds_large": 2048 < longest <= 16384, "global": longest > 16384}[expect_path], longest
+    np.testing.assert_array_equal(radii, oradii)
+    np.testing.assert_array_equal(st["point_list"].cpu().numpy().astype(np.uint32), o.binning()["point_list"])
+    solid, touched = touched_by_fragile(o)
+    assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
+    og = o.backward(dpix)
+    for k in grads:
+        e = _norm_err(grads[k], og[k])
+        assert np.quantile(e[~touched], 0.999) <= GRAD_TOL if (~touched).any() else True, k
+
+
+def test_capacity_overflow_is_detected_and_repaired(monkeypatch):
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_uniform_cloud(5000, 128, 96, seed=9, scale_med=0.05)
+    o, oimg, _ = oracle_render(g, "f32")
+    assert o.num_rendered > 4 * 1024
+    calls = []
+    real = RZ._capacity_for
+
+    def tiny_first(st, P):
+        calls.append(1)
+        return 1024 if len(calls) == 1 else real(st, P)
+
+    monkeypatch.setattr(RZ, "_capacity_for", tiny_first)
+    img, _, _, _ = hip_render(g)
+    assert len(calls) >= 2
+    solid, _ = touched_by_fragile(o)
+    assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
+
+
+def test_deferred_check_mode(monkeypatch):
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_uniform_cloud(5000, 128, 96, seed=9, scale_med=0.05)
+    monkeypatch.setenv("GPSGS_CHECK", "deferred")
+    o, oimg, _ = oracle_render(g, "f32")
+    img, _, _, _ = hip_render(g)
+    solid, _ = touched_by_fragile(o)
+    assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
+    torch.cuda.synchronize()
+    # an overflowing call is reported loudly on the next entry into the module
+    monkeypatch.setattr(RZ, "_capacity_for", lambda st, P: 512)
+    hip_render(g)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="capacity"):
+        hip_render(g)
+    RZ._state.clear()
+
+
+def test_boundary_hazards_h1_h3_inference_and_debug():
+    """CPU (pinned) camera tensors (H1), non-contiguous grad_out (H3), no-grad inference, debug=True."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_scene(256, 30000)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(g[k]).to(dev) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    for k in t:
+        t[k].requires_grad_(True)
+    m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+    rs = RZ.GaussianRasterizationSettings(g["H"], g["W"], g["tanfovx"], g["tanfovy"], torch.tensor([0.0, 0.0, 0.0], device=dev), 1.0,
+                                          torch.from_numpy(g["view"]).pin_memory(), torch.from_numpy(g["proj"]).pin_memory(), 3,
+                                          torch.from_numpy(g["campos"]), False, True)
+    img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"],
+                                           scales=t["scales"], rotations=t["rotations"])
+    gout = torch.randn(g["H"], g["W"], 3, device=dev).permute(2, 0, 1)   # non-contiguous
+    assert not gout.is_contiguous()
+    img.backward(gout)
+    ref_img, _, ref_grads, _ = hip_render(g, gout.contiguous().cpu().numpy())
+    np.testing.assert_array_equal(img.detach().cpu().numpy(), ref_img)
+    for k in t:
+        s = np.abs(ref_grads[k]).max()
+        assert np.abs(t[k].grad.cpu().numpy() - ref_grads[k]).max() <= 2e-4 * s
+    assert m2.grad is not None and m2.grad.shape == (30000, 3) and float(m2.grad[:, 2].abs().max()) == 0.0
+    assert radii.dtype == torch.int32 and not radii.requires_grad
+    with torch.no_grad():
+        img2, _ = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    np.testing.assert_array_equal(img2.cpu().numpy(), ref_img)
+
+
+def test_render_api_pts2render_matches_oracle_on_reference_compaction():
+    """pts2render(data, bg) end to end on the golden data dict: compaction as the reference's (fixture from the reference),
+    raster as the oracle."""
+    import torch
+    from gps_gaussian_amd import render_api
+    from gps_gaussian_amd import synthetic as S
+    gold = np.load(os.path.join(GOLDEN, "pts2render_golden.npz"))
+    dev = torch.device("cuda:0")
+    B, side = 2, 64
+    data = {}
+    for v in ("lmain", "rmain"):
+        data[v] = {k: torch.from_numpy(gold["%s_%s" % (v, k)]).to(dev) for k in ("img", "xyz", "pts_valid", "rot_maps", "scale_maps", "opacity_maps")}
+        data[v]["xyz"] = data[v]["xyz"] * 0.1 + torch.tensor([0.0, 0.0, 2.0], device=dev)   # put the random points in front of the camera
+        data[v]["scale_maps"] = data[v]["scale_maps"] * 5
+    from conftest import simple_scene
+    cam = simple_scene(side, side, 48.0)
+    data["novel_view"] = dict(
+        FovX=torch.tensor([2 * np.arctan(cam["tanfovx"])] * B), FovY=torch.tensor([2 * np.arctan(cam["tanfovy"])] * B),
+        width=torch.tensor([side] * B), height=torch.tensor([side] * B),
+        world_view_transform=torch.from_numpy(cam["view"])[None].repeat(B, 1, 1),       # CPU tensors, as in training (H1)
+        full_proj_transform=torch.from_numpy(cam["proj"])[None].repeat(B, 1, 1), camera_center=torch.zeros(B, 3))
+    out = render_api.pts2render(data, [0.2, 0.3, 0.4])["novel_view"]["img_pred"]
+    assert tuple(out.shape) == (B, 3, side, side)
+    for i in range(B):
+        scene = dict(cam)
+        scene["bg"] = np.array([0.2, 0.3, 0.4], np.float32)
+        scene["means3D"] = (gold["out%d_xyz" % i] * 0.1 + np.array([0, 0, 2.0], np.float32)).astype(np.float32)
+        scene["colors"] = gold["out%d_rgb" % i]
+        scene["rotations"] = gold["out%d_rot" % i]
+        scene["scales"] = gold["out%d_scale" % i] * 5
+        scene["opacities"] = gold["out%d_opacity" % i]
+        o, oimg, _ = oracle_render(scene, "f32")
+        solid, _ = touched_by_fragile(o)
+        assert np.abs(out[i].cpu().numpy() - oimg).max(0)[solid].max() <= RGB_TOL

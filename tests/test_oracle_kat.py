@@ -1,0 +1,62 @@
+"""CPU: pins oracle/gsr_oracle.c (fp32 and fp64 builds) against analytic known answers and an independent autograd restatement."""
+import numpy as np
+import pytest
+
+import kat_cases
+from conftest import oracle_render
+
+import gps_gaussian_amd  # noqa: F401
+from gps_gaussian_amd import synthetic as S
+from oracle.gsr_oracle import OracleRasterizer
+from oracle.gsr_torch_ref import grads_ref
+
+
+def _render(kind):
+    def f(scene):
+        o, img, radii = oracle_render(scene, kind)
+        extra = o.binning() if scene["means3D"].shape[0] else None
+        return img, radii, extra
+    f.fp32_decisions = kind == "f32"
+    return f
+
+
+@pytest.mark.parametrize("case", kat_cases.ALL, ids=lambda c: c.__name__)
+@pytest.mark.parametrize("kind", ["f32", "f64"])
+def test_known_answers(case, kind):
+    # inputs are fp32-rounded (0.05f, 0.7f ...), so even the fp64 build is compared at ~1e-6
+    case(_render(kind), 2e-6 if kind == "f32" else 5e-7)
+
+
+@pytest.mark.parametrize("seed,W,H,n,scale", [(0, 40, 36, 120, 0.05), (1, 48, 32, 200, 0.15), (2, 33, 47, 150, 0.02)])
+def test_backward_matches_independent_autograd(seed, W, H, n, scale):
+    """The hand-derived backward of the C oracle (fp64) equals torch.autograd through an independent forward restatement."""
+    g = S.make_uniform_cloud(n, W, H, seed=seed, scale_med=scale, z_range=(0.3, 4.0))
+    dpix = np.random.default_rng(seed).standard_normal((3, H, W))
+    o, img, radii = oracle_render(g, "f64")
+    gr = o.backward(dpix)
+    img2, radii2, gr2 = grads_ref(g, W, H, g["tanfovx"], g["tanfovy"], dpix)
+    assert (radii == radii2).all() and (radii > 0).sum() > n // 3
+    np.testing.assert_allclose(img, img2, atol=1e-12)
+    for k in gr:
+        np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
+
+
+def test_fp32_and_fp64_builds_agree_on_config1():
+    """BASELINE config 1 (256^2, ~30k Gaussians, CPU only): the two builds agree away from branch thresholds."""
+    g = S.make_scene(256, 30000)
+    o32, i32, r32 = oracle_render(g, "f32")
+    o64, i64, r64 = oracle_render(g, "f64", decisions=o32.geom())
+    assert (r32 == r64).all() and o32.num_rendered == o64.num_rendered
+    solid = o32.fragility() > 1e-4
+    assert solid.mean() > 0.999
+    assert np.abs(i32 - i64).max(0)[solid].max() < 1e-4  # the north-star RGB tolerance
+    assert (i32.mean() > 0.05) and (r32 > 0).all()
+
+
+def test_decisions_override_is_idempotent():
+    g = S.make_uniform_cloud(3000, 96, 80, seed=5, scale_med=0.03)
+    o, img, radii = oracle_render(g, "f32")
+    o2, img2, radii2 = oracle_render(g, "f32", decisions=o.geom())
+    assert (radii == radii2).all()
+    np.testing.assert_array_equal(img, img2)
+    np.testing.assert_array_equal(o.binning()["point_list"], o2.binning()["point_list"])
