@@ -20,7 +20,7 @@ STAGES = ("preprocess", "scan", "scatter", "sort", "composite_fwd", "composite_b
 
 class GsrHeader(C.Structure):
     _fields_ = [("num_rendered", C.c_uint64), ("overflow", C.c_uint32), ("max_tile_count", C.c_uint32),
-                ("num_visible", C.c_uint32), ("reserved", C.c_uint32 * 11)]
+                ("num_busy_wgs", C.c_uint32), ("reserved", C.c_uint32 * 11)]
 
 
 _lib = None

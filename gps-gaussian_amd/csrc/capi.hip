@@ -46,14 +46,14 @@ struct StageTimer {  // RAII: records an event pair around one stage when timing
 };
 
 __global__ void k_export(int P, int T, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ tile_offset, float *depth,
-                         float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges) {
+                         float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges) {  // T = number of bins
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < P) {
         const GsrSplat s = splats[i];
         if (depth) depth[i] = s.depth;
         if (xy) { xy[2 * i] = s.x; xy[2 * i + 1] = s.y; }
         if (conic_opacity) { conic_opacity[4 * i] = s.A; conic_opacity[4 * i + 1] = s.B; conic_opacity[4 * i + 2] = s.C; conic_opacity[4 * i + 3] = s.op; }
-        if (rect) { rect[4 * i] = s.rect_lo & 0xffff; rect[4 * i + 1] = s.rect_lo >> 16; rect[4 * i + 2] = s.rect_hi & 0xffff; rect[4 * i + 3] = s.rect_hi >> 16; }
+        if (rect) { rect[4 * i] = s.bin_lo & 0xffff; rect[4 * i + 1] = s.bin_lo >> 16; rect[4 * i + 2] = s.bin_hi & 0xffff; rect[4 * i + 3] = s.bin_hi >> 16; }
     }
     if (i < T && tile_ranges) {
         const uint32_t a = tile_offset[i], b = tile_offset[i + 1];
@@ -86,52 +86,54 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     GsrHeader *hdr = reinterpret_cast<GsrHeader *>(at(workspace, L.header));
-    uint32_t *tile_count = reinterpret_cast<uint32_t *>(at(workspace, L.tile_count));
-    uint32_t *tile_offset = reinterpret_cast<uint32_t *>(at(workspace, L.tile_offset));
-    uint32_t *tile_cursor = reinterpret_cast<uint32_t *>(at(workspace, L.tile_cursor));
+    uint32_t *bin_count = reinterpret_cast<uint32_t *>(at(workspace, L.bin_count));
+    uint32_t *bin_offset = reinterpret_cast<uint32_t *>(at(workspace, L.bin_offset));
+    uint32_t *bin_cursor = reinterpret_cast<uint32_t *>(at(workspace, L.bin_cursor));
+    uint32_t *wg_order = reinterpret_cast<uint32_t *>(at(workspace, L.wg_order));
+    uint4 *scan_part = reinterpret_cast<uint4 *>(at(workspace, L.scan_part));
     GsrSplat *splats = reinterpret_cast<GsrSplat *>(at(workspace, L.splats));
     uint64_t *keys = reinterpret_cast<uint64_t *>(at(workspace, L.keys));
     uint32_t *point_list = reinterpret_cast<uint32_t *>(at(workspace, L.point_list));
     float *final_T = reinterpret_cast<float *>(at(workspace, L.final_T));
     uint32_t *n_contrib = reinterpret_cast<uint32_t *>(at(workspace, L.n_contrib));
 
-    // header + tile_count are adjacent: one memset
-    if (hipMemsetAsync(hdr, 0, L.tile_offset - L.header, s) != hipSuccess) return GPSGS_E_LAUNCH;
+    // header + bin_count are adjacent: one memset
+    if (hipMemsetAsync(hdr, 0, L.bin_offset - L.header, s) != hipSuccess) return GPSGS_E_LAUNCH;
     if (P == 0) {  // upstream returns its zero-initialised image (NOT the background) when there is nothing to draw
         if (hipMemsetAsync(out_color, 0, sizeof(float) * 3 * (size_t)width * height, s) != hipSuccess) return GPSGS_E_LAUNCH;
-        if (hipMemsetAsync(tile_offset, 0, (size_t)(L.T + 1) * 4, s) != hipSuccess) return GPSGS_E_LAUNCH;
+        if (hipMemsetAsync(bin_offset, 0, (size_t)(L.NB + 1) * 4, s) != hipSuccess) return GPSGS_E_LAUNCH;
         return check(s, flags);
     }
     GsrFwdParams q;
-    q.P = P; q.W = width; q.H = height; q.gx = L.gx; q.gy = L.gy;
+    q.P = P; q.W = width; q.H = height; q.gx = L.gx; q.gy = L.gy; q.bx = L.bx; q.by = L.by; q.bx_real = L.bx_real;
     q.means3D = means3D; q.colors = colors; q.opacities = opacities; q.scales = scales; q.rotations = rotations;
     q.scale_modifier = scale_modifier; q.tanfovx = tanfovx; q.tanfovy = tanfovy;
-    q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity;
+    q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity; q.dbg = flags >> 8;
 
     int rc;
     {
         StageTimer t(flags, GSR_STAGE_PREPROCESS, s);
-        gsr_launch_preprocess(q, splats, tile_count, hdr, s);
+        gsr_launch_preprocess(q, splats, bin_count, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCAN, s);
-        gsr_launch_scan(tile_count, tile_offset, tile_cursor, L.T, instance_capacity, hdr, s);
+        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, L.gx, splats, tile_cursor, keys, instance_capacity, hdr, s);
+        gsr_launch_scatter(P, L.bx, splats, bin_cursor, keys, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SORT, s);
-        gsr_launch_sort(L.T, tile_offset, keys, point_list, hdr, s);
+        gsr_launch_sort(L.NB, bin_offset, keys, point_list, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
-        gsr_launch_composite_fwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+        gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
     }
     return check(s, flags);
 }
@@ -152,7 +154,8 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const GsrHeader *hdr = reinterpret_cast<const GsrHeader *>(at(workspace, L.header));
-    const uint32_t *tile_offset = reinterpret_cast<const uint32_t *>(at(workspace, L.tile_offset));
+    const uint32_t *bin_offset = reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset));
+    const uint32_t *wg_order = reinterpret_cast<const uint32_t *>(at(workspace, L.wg_order));
     const GsrSplat *splats = reinterpret_cast<const GsrSplat *>(at(workspace, L.splats));
     const uint32_t *point_list = reinterpret_cast<const uint32_t *>(at(workspace, L.point_list));
     const float *final_T = reinterpret_cast<const float *>(at(workspace, L.final_T));
@@ -163,7 +166,7 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     int rc;
     {
         StageTimer t(flags, GSR_STAGE_COMPOSITE_BWD, s);
-        gsr_launch_composite_bwd(width, height, L.gx, L.gy, splats, tile_offset, point_list, bg, dL_dpix, final_T, n_contrib, gacc, hdr, s);
+        gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, gacc, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     GsrBwdParams b;
@@ -208,10 +211,10 @@ extern "C" int gsr_export_state(const void *workspace, int P, int width, int hei
     if (!workspace || P < 0 || width <= 0 || height <= 0) return GPSGS_E_INVALID;
     const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
     hipStream_t s = (hipStream_t)stream;
-    const int n = P > L.T ? P : L.T;
+    const int n = P > L.NB ? P : L.NB;
     if (n > 0)
-        hipLaunchKernelGGL(k_export, dim3((n + 255) / 256), dim3(256), 0, s, P, L.T, reinterpret_cast<const GsrSplat *>(at(workspace, L.splats)),
-                           reinterpret_cast<const uint32_t *>(at(workspace, L.tile_offset)), depth, xy, conic_opacity, rect, tile_ranges);
+        hipLaunchKernelGGL(k_export, dim3((n + 255) / 256), dim3(256), 0, s, P, L.NB, reinterpret_cast<const GsrSplat *>(at(workspace, L.splats)),
+                           reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), depth, xy, conic_opacity, rect, tile_ranges);
     const size_t npix = (size_t)width * height;
     if (point_list && instance_capacity > 0)
         (void)hipMemcpyAsync(point_list, at(workspace, L.point_list), (size_t)instance_capacity * 4, hipMemcpyDeviceToDevice, s);

@@ -1,13 +1,15 @@
-// gsr_binning.hip -- tile binning and per-tile depth ordering for gfx950.
+// gsr_binning.hip -- bin assignment and per-bin depth ordering for gfx950.
 //
 // Upstream builds one global list of (tile<<32 | depth) keys and radix-sorts all R of them through HBM (~6 passes
-// of 24 B/instance) after a blocking D2H read of R.  Here the tile part of the key is
+// of 24 B/instance) after a blocking D2H read of R.  Here the bin part of the key is
 // resolved by construction instead of by sorting:
-//   k_scan     exclusive scan of the per-tile counts (written by k_preprocess) -> tile_offset, R, overflow flag;
-//              R never leaves the device.
-//   k_scatter  each Gaussian drops (depth_bits<<32 | id) into its tiles' segments (one returning atomic per
-//              instance on a per-tile cursor).
-//   k_sort_*   one workgroup per tile sorts its segment in LDS with an ascending-only bitonic network on the
+//   k_scan_a/b two-phase parallel exclusive scan of the per-bin counts (written by k_preprocess into one-counter-per-
+//              128-B-line storage) -> bin_offset, cursors, R, overflow flag; R never leaves the device.  The same pass
+//              emits wg_order: compositing workgroups with work first (so every CU starts on real work and the empty
+//              ones drain in the gaps), in image order within each class (keeps neighbouring bins on neighbouring CUs).
+//   k_scatter  each Gaussian drops (depth_bits<<32 | id) into its bins' segments; slots are reserved with ONE returning
+//              global atomic per (workgroup, bin) after an LDS histogram (gsr_block_bin), not one per instance.
+//   k_sort_*   one workgroup per bin sorts its segment in LDS with an ascending-only bitonic network on the
 //              64-bit key.  Keys are unique (id in the low word) so the result is deterministic and equals
 //              upstream's stable radix order: depth ascending, ties by Gaussian index.
 //              Segments longer than the LDS capacity fall back to the same network run in global memory.
@@ -16,76 +18,114 @@
 
 namespace {
 
-constexpr int SCAN_THREADS = 1024;
+constexpr int SB = GSR_SCAN_BLOCK;  // 1024 bins per scan block
 
-// Single-workgroup scan: T is at most a few 10^4 tiles (16,384 at 2048^2), i.e. a few microseconds.
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_offset,
-                                                       uint32_t *__restrict__ tile_cursor, int T, int64_t cap,
-                                                       GsrHeader *__restrict__ hdr) {
-    __shared__ uint32_t wsum[SCAN_THREADS / 64];
-    __shared__ uint32_t wmax[SCAN_THREADS / 64];
-    __shared__ uint32_t carry_s;
+// block-wide exclusive scan of one uint per thread (1024 threads); returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum /*[16]*/, uint32_t *total) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    uint32_t vmax = 0;
-    __syncthreads();
-    for (int base = 0; base < T; base += SCAN_THREADS) {
-        const int i = base + tid;
-        const uint32_t v = i < T ? tile_count[i] : 0u;
-        vmax = v > vmax ? v : vmax;
-        uint32_t x = v;  // inclusive wave scan
+    uint32_t x = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wsum[wid] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + woff + x - v;
-        if (i < T) {
-            tile_offset[i] = excl;
-            tile_cursor[i] = excl;
-        }
-        __syncthreads();
-        if (tid == SCAN_THREADS - 1) carry_s = excl + v;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
     }
+    __syncthreads();  // wsum may still be read from a previous call
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SB / 64; w++) {
+        const uint32_t s = wsum[w];
+        if (w < wid) woff += s;
+        tot += s;
+    }
+    *total = tot;
+    return woff + x - v;
+}
+
+// phase A: per block of 1024 bins -> {sum of counts, number of busy compositing workgroups, max count}
+__global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part, int NB) {
+    __shared__ uint32_t red[3][SB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.x * SB + tid;
+    const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
+    const unsigned long long nz = __ballot(c > 0);
+    // workgroup w = bins 4w..4w+3 = 4 consecutive lanes; counted once by its first lane
+    const uint32_t busy = ((lane & 3) == 0 && ((nz >> lane) & 0xFull)) ? 1u : 0u;
+    uint32_t s = c, nb = busy, mx = c;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t y = __shfl_xor(vmax, d, 64);
-        vmax = y > vmax ? y : vmax;
+        s += __shfl_xor(s, d, 64);
+        nb += __shfl_xor(nb, d, 64);
+        const uint32_t y = __shfl_xor(mx, d, 64);
+        mx = y > mx ? y : mx;
     }
-    if (lane == 0) wmax[wid] = vmax;
+    if (lane == 0) { red[0][wid] = s; red[1][wid] = nb; red[2][wid] = mx; }
     __syncthreads();
     if (tid == 0) {
-        uint32_t m = 0;
-        for (int w = 0; w < SCAN_THREADS / 64; w++) m = wmax[w] > m ? wmax[w] : m;
-        const uint32_t R = carry_s;
-        tile_offset[T] = R;
-        hdr->num_rendered = R;
-        hdr->overflow = ((int64_t)R > cap) ? 1u : 0u;
-        hdr->max_tile_count = m;
+        uint32_t ts = 0, tb = 0, tm = 0;
+        for (int w = 0; w < SB / 64; w++) { ts += red[0][w]; tb += red[1][w]; tm = red[2][w] > tm ? red[2][w] : tm; }
+        part[blockIdx.x] = make_uint4(ts, tb, tm, 0u);
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter(int P, int gx, const GsrSplat *__restrict__ splats, uint32_t *__restrict__ tile_cursor,
-                                                 uint64_t *__restrict__ keys, const GsrHeader *__restrict__ hdr) {
+// phase B: every block re-derives its prefix from the (few) block partials, then scans its own 1024 bins
+__global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, const uint4 *__restrict__ part,
+                                               uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
+                                               uint32_t *__restrict__ wg_order, int NB, int nblocks, int64_t cap,
+                                               GsrHeader *__restrict__ hdr) {
+    __shared__ uint32_t wsum[SB / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t pre_sum = 0, pre_busy = 0, tot_sum = 0, tot_busy = 0, tot_max = 0;
+    for (int i = 0; i < nblocks; i++) {  // wave-uniform loads of a handful of uint4
+        const uint4 p = part[i];
+        if (i < (int)blockIdx.x) { pre_sum += p.x; pre_busy += p.y; }
+        tot_sum += p.x; tot_busy += p.y; tot_max = p.z > tot_max ? p.z : tot_max;
+    }
+    const int b = blockIdx.x * SB + tid;
+    const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
+    uint32_t blk_total;
+    const uint32_t off = pre_sum + block_exscan(c, wsum, &blk_total);
+    if (b < NB) {
+        bin_offset[b] = off;
+        bin_cursor[(size_t)b * GSR_CPAD] = off;
+    }
+    // work-ordered workgroup list
+    const unsigned long long nz = __ballot(c > 0);
+    const bool is_wg_lead = (lane & 3) == 0 && b < NB;
+    const bool busy = is_wg_lead && ((nz >> lane) & 0xFull);
+    uint32_t blk_busy;
+    const uint32_t bpos = block_exscan(busy ? 1u : 0u, wsum, &blk_busy);
+    if (is_wg_lead) {
+        const uint32_t w = (uint32_t)b / GSR_BINS_PER_WG;
+        const uint32_t nbusy_before = pre_busy + bpos;
+        wg_order[busy ? nbusy_before : tot_busy + (w - nbusy_before)] = w;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        bin_offset[NB] = tot_sum;
+        hdr->num_rendered = tot_sum;
+        hdr->overflow = ((int64_t)tot_sum > cap) ? 1u : 0u;
+        hdr->max_tile_count = tot_max;
+        hdr->num_busy_wgs = tot_busy;
+    }
+}
+
+__global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats,
+                                                            uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
+                                                            const GsrHeader *__restrict__ hdr) {
     if (hdr->overflow) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const float4 c = reinterpret_cast<const float4 *>(splats + i)[2];
-    const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
-    const int r0x = lo & 0xffff, r0y = lo >> 16, r1x = hi & 0xffff, r1y = hi >> 16;
-    if (r1x <= r0x || r1y <= r0y) return;
-    const uint64_t key = ((uint64_t)__float_as_uint(c.y) << 32) | (uint32_t)i;
-    for (int ty = r0y; ty < r1y; ty++)
-        for (int tx = r0x; tx < r1x; tx++) {
-            const uint32_t pos = atomicAdd(&tile_cursor[ty * gx + tx], 1u);
-            keys[pos] = key;
-        }
+    const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
+    uint32_t lo = 0, hi = 0;
+    uint64_t key = 0;
+    if (i < P) {
+        const float4 c = reinterpret_cast<const float4 *>(splats + i)[2];
+        lo = __float_as_uint(c.z);
+        hi = __float_as_uint(c.w);
+        key = ((uint64_t)__float_as_uint(c.y) << 32) | (uint32_t)i;
+    }
+    gsr_block_bin<true>(
+        lo, hi, bx, [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
+        [&](uint32_t pos) { keys[pos] = key; });
 }
 
 // ascending compare-exchange on LDS / global arrays, virtual +inf padding beyond n (comparators with j >= n are no-ops)
@@ -128,16 +168,9 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
     return p;
 }
 
-// One workgroup per tile; handles segments with lo < n <= CAP in LDS; if GLOBAL_FALLBACK also n > CAP in HBM.
 template <int THREADS, int CAP, bool GLOBAL_FALLBACK>
-__global__ __launch_bounds__(THREADS) void k_sort(const uint32_t *__restrict__ tile_offset, uint64_t *__restrict__ keys,
-                                                  uint32_t *__restrict__ point_list, uint32_t lo, const GsrHeader *__restrict__ hdr) {
-    __shared__ uint64_t sk[CAP];
-    if (hdr->overflow) return;
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const uint32_t off = tile_offset[t], n = tile_offset[t + 1] - off;
-    if (n <= lo) return;
-    if (n > (uint32_t)CAP && !GLOBAL_FALLBACK) return;
+__device__ __forceinline__ void sort_one_bin(uint64_t *sk, uint32_t off, uint32_t n, uint64_t *__restrict__ keys,
+                                             uint32_t *__restrict__ point_list, int tid) {
     uint64_t *seg = keys + off;
     if (n == 1) {
         if (tid == 0) point_list[off] = (uint32_t)seg[0];
@@ -149,31 +182,55 @@ __global__ __launch_bounds__(THREADS) void k_sort(const uint32_t *__restrict__ t
         __syncthreads();
         bitonic_sort<THREADS>(sk, n, n2, tid);
         for (uint32_t i = tid; i < n; i += THREADS) point_list[off + i] = (uint32_t)sk[i];
-    } else {
-        // rare: tile list longer than LDS; same network in global memory (workgroup-coherent through L2/L1 of this CU)
+    } else if (GLOBAL_FALLBACK) {
+        // rare: bin list longer than LDS; same network in global memory (one workgroup, coherent through its CU)
         volatile uint64_t *vs = seg;
         bitonic_sort<THREADS>(vs, n, n2, tid);
         for (uint32_t i = tid; i < n; i += THREADS) point_list[off + i] = (uint32_t)vs[i];
     }
 }
 
+// lists of 1..2048 keys: one 256-thread workgroup per bin, 16 KiB LDS
+__global__ __launch_bounds__(256) void k_sort_small(const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
+                                                    uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
+    __shared__ uint64_t sk[2048];
+    if (hdr->overflow) return;
+    const uint32_t off = bin_offset[blockIdx.x], n = bin_offset[blockIdx.x + 1] - off;
+    if (n == 0 || n > 2048u) return;
+    sort_one_bin<256, 2048, false>(sk, off, n, keys, point_list, threadIdx.x);
+}
+
+// lists longer than 2048 keys are rare: a small persistent grid of 1024-thread workgroups (128 KiB LDS each) strides
+// over the bins and picks them up (launching one big workgroup per bin just to exit cost ~18 us at 16,384 bins)
+__global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
+                                                     uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
+    __shared__ uint64_t sk[16384];
+    if (hdr->overflow || hdr->max_tile_count <= 2048u) return;
+    for (int b = blockIdx.x; b < NB; b += gridDim.x) {
+        const uint32_t off = bin_offset[b], n = bin_offset[b + 1] - off;  // wave-uniform
+        if (n > 2048u) {
+            sort_one_bin<1024, 16384, true>(sk, off, n, keys, point_list, threadIdx.x);
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
-void gsr_launch_scan(uint32_t *tile_count, uint32_t *tile_offset, uint32_t *tile_cursor, int T, int64_t cap, GsrHeader *hdr, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, tile_count, tile_offset, tile_cursor, T, cap, hdr);
+void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
+                     int64_t cap, GsrHeader *hdr, hipStream_t s) {
+    const int nblocks = (NB + SB - 1) / SB;
+    hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB);
+    hipLaunchKernelGGL(k_scan_b, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr);
 }
 
-void gsr_launch_scatter(int P, int gx, const GsrSplat *splats, uint32_t *tile_cursor, uint64_t *keys, int64_t cap, const GsrHeader *hdr,
-                        hipStream_t s) {
-    (void)cap;
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, splats, tile_cursor, keys, hdr);
+    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, bin_cursor, keys, hdr);
 }
 
-void gsr_launch_sort(int T, const uint32_t *tile_offset, uint64_t *keys, uint32_t *point_list, const GsrHeader *hdr, hipStream_t s) {
-    if (T <= 0) return;
-    // two size classes so that typical tiles keep several workgroups per CU: <= 2048 keys (16 KiB LDS) and
-    // <= 16384 keys (128 KiB LDS, 1024 threads); anything longer sorts in global memory inside the second kernel.
-    hipLaunchKernelGGL((k_sort<256, 2048, false>), dim3(T), dim3(256), 0, s, tile_offset, keys, point_list, 0u, hdr);
-    hipLaunchKernelGGL((k_sort<1024, 16384, true>), dim3(T), dim3(1024), 0, s, tile_offset, keys, point_list, 2048u, hdr);
+void gsr_launch_sort(int NB, const uint32_t *bin_offset, uint64_t *keys, uint32_t *point_list, const GsrHeader *hdr, hipStream_t s) {
+    if (NB <= 0) return;
+    hipLaunchKernelGGL(k_sort_small, dim3(NB), dim3(256), 0, s, bin_offset, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_large, dim3(NB < 256 ? NB : 256), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

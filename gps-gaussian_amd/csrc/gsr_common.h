@@ -1,41 +1,58 @@
 // gsr_common.h -- shared device-side types and the workspace layout of the gfx950 rasteriser.
 //
+// Work decomposition (MI355X-first): the image is cut into 8x8-pixel BINS, one wave64 per bin (lane = pixel).  A
+// Gaussian is listed in a bin iff the bin lies inside upstream's 16x16-tile rect (the semantic membership rule,
+// SURVEY.md section 9.4.1) AND inside the axis-aligned bounding box of its alpha >= 1/255 level set (pairs outside that box
+// are guaranteed to fail the alpha test, so dropping them is exact).  Compared with one 256-thread workgroup per
+// 16x16 tile this gives ~2.6x shorter per-pixel dependency chains, 4x more independent work items, no workgroup
+// barriers at all, and no wave ever iterates over a splat that cannot touch its pixels.
+//
 // Data layout in HBM (all carved from ONE caller-owned workspace, 256-byte aligned sections):
-//   header        GsrHeader (64 B)                       R needed, overflow flag, stats
-//   splats[P]     48-byte records {x,y,A,B | C,op,r,g | b,depth,rect_lo,rect_hi}: everything the compositing
-//                 kernels gather per instance sits in one record (1-2 cache lines per gather instead of 3 arrays)
-//   tile_count[T], tile_offset[T+1], tile_cursor[T]      u32 per 16x16 tile
-//   keys[cap]     u64 (depth_bits << 32 | gaussian id), binned per tile, sorted in LDS per tile
+//   header         GsrHeader (64 B)                      R needed, overflow flag, stats
+//   bin_count[NB*32], bin_cursor[NB*32]                  u32 per bin, ONE COUNTER PER 128-BYTE LINE: device-scope atomics on
+//                                                        neighbouring bins would otherwise serialise on a shared line
+//   bin_offset[NB+1], wg_order[NB/4], scan_part[...]     dense exclusive offsets; work-ordered workgroup list (busy first)
+//   splats[P]      48-byte records {x,y,A,B | C,op,r,g | b,depth,binrect_lo,binrect_hi}: everything the compositing
+//                  kernels gather per instance sits in one record (1-2 cache lines per gather instead of 3 arrays)
+//   keys[cap]      u64 (depth_bits << 32 | gaussian id), binned, then sorted in LDS per bin
 //   point_list[cap] u32 sorted gaussian ids (what the compositing kernels walk)
 //   final_T[H*W], n_contrib[H*W]                         per-pixel state kept for the backward
-//   gacc[P]       48-byte records of backward partial sums {dcolor rgb, dmean2D xy, dconic xx xy yy, dopacity}
+//   gacc[P]        48-byte records of backward partial sums {dcolor rgb, dmean2D xy, dconic xx xy yy, dopacity}
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/gpsgs.h"
 
-#define GSR_TILE 16
-#define GSR_TILE_PIX 256
+#define GSR_TILE 16 // upstream's tile edge: defines rect membership and the reported radii semantics
+#define GSR_BIN 8   // our work-item edge: one wave64 per 8x8 pixels
+#define GSR_BINS_PER_WG 4 // a 256-thread workgroup = 4 horizontally adjacent bins (32x8 px: full 128-B output lines)
+#define GSR_CPAD 32       // u32 stride of the padded per-bin counters / cursors (one 128-byte line each)
+#define GSR_SCAN_BLOCK 1024
 
 struct __attribute__((aligned(16))) GsrSplat {
-    float x, y, A, B;          // pixel-space mean, conic xx, xy
-    float C, op, r, g;         // conic yy, opacity, colour
-    float b, depth;            // colour, view-space depth
-    uint32_t rect_lo, rect_hi; // minx | miny<<16 , maxx | maxy<<16  (tile units; empty rect = culled)
+    float x, y, A, B;        // pixel-space mean, conic xx, xy
+    float C, op, r, g;       // conic yy, opacity, colour
+    float b, depth;          // colour, view-space depth
+    uint32_t bin_lo, bin_hi; // bx0 | by0<<16 , bx1 | by1<<16  (bin units, exclusive upper; empty = not listed anywhere)
 };
 static_assert(sizeof(GsrSplat) == 48, "splat record must be 48 bytes");
 
 struct __attribute__((aligned(16))) GsrGradAcc {
-    float dr, dg, db, dmx; // dL/dcolor, dL/dmean2D.x (NDC-scaled)
+    float dr, dg, db, dmx;    // dL/dcolor, dL/dmean2D.x (NDC-scaled)
     float dmy, cxx, cxy, cyy; // dL/dmean2D.y, dL/dconic (xy holds HALF the true off-diagonal gradient, like upstream)
     float dop, pad0, pad1, pad2;
 };
 static_assert(sizeof(GsrGradAcc) == 48, "grad record must be 48 bytes");
 
 struct GsrLayout {
-    size_t header, splats, tile_count, tile_offset, tile_cursor, keys, point_list, final_T, n_contrib, gacc, total;
-    int gx, gy, T;
+    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, keys, point_list, final_T, n_contrib, gacc, total;
+    int gx, gy;   // 16x16 tile grid (upstream semantics)
+    int bx, by;   // bin grid: bx = ceil(W/8) rounded up to a multiple of GSR_BINS_PER_WG, by = ceil(H/8)
+    int bx_real;  // ceil(W/8)
+    int NB;       // bx * by
+    int NWG;      // NB / GSR_BINS_PER_WG compositing workgroups
+    int NSB;      // scan blocks = ceil(NB / GSR_SCAN_BLOCK)
 };
 
 static inline size_t gsr_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -44,43 +61,119 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     GsrLayout L;
     L.gx = (W + GSR_TILE - 1) / GSR_TILE;
     L.gy = (H + GSR_TILE - 1) / GSR_TILE;
-    L.T = L.gx * L.gy;
+    L.bx_real = (W + GSR_BIN - 1) / GSR_BIN;
+    L.bx = (L.bx_real + GSR_BINS_PER_WG - 1) / GSR_BINS_PER_WG * GSR_BINS_PER_WG;
+    L.by = (H + GSR_BIN - 1) / GSR_BIN;
+    L.NB = L.bx * L.by;
+    L.NWG = L.NB / GSR_BINS_PER_WG;
+    L.NSB = (L.NB + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
     size_t o = 0;
-    const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.T > 0 ? L.T : 1), c = (size_t)(cap > 0 ? cap : 1);
+    const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.NB > 0 ? L.NB : 1), c = (size_t)(cap > 0 ? cap : 1);
     const size_t npix = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
-    L.header = o;      o = gsr_align_up(o + sizeof(GsrHeader));   // header + tile_count are zeroed by ONE memset
-    L.tile_count = o;  o = gsr_align_up(o + t * 4);
-    L.tile_offset = o; o = gsr_align_up(o + (t + 1) * 4);
-    L.tile_cursor = o; o = gsr_align_up(o + t * 4);
-    L.splats = o;      o = gsr_align_up(o + p * sizeof(GsrSplat));
-    L.keys = o;        o = gsr_align_up(o + c * 8);
-    L.point_list = o;  o = gsr_align_up(o + c * 4);
-    L.final_T = o;     o = gsr_align_up(o + npix * 4);
-    L.n_contrib = o;   o = gsr_align_up(o + npix * 4);
-    L.gacc = o;        o = gsr_align_up(o + p * sizeof(GsrGradAcc));
+    L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + bin_count are zeroed by ONE memset
+    L.bin_count = o;  o = gsr_align_up(o + t * 4 * GSR_CPAD);
+    L.bin_offset = o; o = gsr_align_up(o + (t + 1) * 4);
+    L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);
+    L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
+    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 16);
+    L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
+    L.keys = o;       o = gsr_align_up(o + c * 8);
+    L.point_list = o; o = gsr_align_up(o + c * 4);
+    L.final_T = o;    o = gsr_align_up(o + npix * 4);
+    L.n_contrib = o;  o = gsr_align_up(o + npix * 4);
+    L.gacc = o;       o = gsr_align_up(o + p * sizeof(GsrGradAcc));
     L.total = o;
     return L;
 }
 
+#if defined(__HIPCC__)
+// Workgroup-aggregated binning.  Same-address device atomics serialise at ~0.1-0.2 us each on MI355X (measured,
+// tools/ubench/atomic_bench*.hip), and a body bin receives ~450 instances, so per-instance -- or even per-wave --
+// atomics on the per-bin counters cost >100 us.  Pixel-Gaussians arrive in source-raster order, so the bins touched
+// by one 1024-thread workgroup form a small rectangle of the bin grid: the workgroup histograms its instances into a
+// direct-indexed LDS table over that rectangle (ds_add, which also hands every instance its rank) and then issues ONE
+// global atomic per touched bin (reserve(bin, count) -> base).  emit(pos) is called once per instance with its slot.
+// Incoherent input (bounding rectangle > GSR_BLOCK_TAB bins) falls back to one global atomic per instance.
+#define GSR_BIN_THREADS 1024
+#define GSR_BLOCK_TAB 2048
+template <bool EMIT, typename Reserve, typename Emit>
+__device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, Reserve reserve, Emit emit) {
+    __shared__ int s_box[4];
+    __shared__ uint32_t s_cnt[GSR_BLOCK_TAB];
+    __shared__ uint32_t s_base[EMIT ? GSR_BLOCK_TAB : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
+    const bool has = (x1 > x0) && (y1 > y0);
+    if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
+    int mnx = has ? x0 : 0x7fffffff, mny = has ? y0 : 0x7fffffff, mxx = has ? x1 : -1, mxy = has ? y1 : -1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, d, 64)); mny = min(mny, __shfl_xor(mny, d, 64));
+        mxx = max(mxx, __shfl_xor(mxx, d, 64)); mxy = max(mxy, __shfl_xor(mxy, d, 64));
+    }
+    __syncthreads();
+    if (lane == 0 && mxx >= 0) {
+        atomicMin(&s_box[0], mnx); atomicMin(&s_box[1], mny); atomicMax(&s_box[2], mxx); atomicMax(&s_box[3], mxy);
+    }
+    __syncthreads();
+    const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2] - bx0, bh = s_box[3] - by0;
+    if (s_box[2] < 0) return;  // nothing listed in this workgroup (uniform)
+    const int area = bw * bh;
+    if (area > GSR_BLOCK_TAB) {  // incoherent input: plain per-instance atomics (uniform branch)
+        if (has)
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) {
+                    const uint32_t pos = reserve(y * bx + x, 1u);
+                    if (EMIT) emit(pos);
+                }
+        return;
+    }
+    for (int t = tid; t < area; t += GSR_BIN_THREADS) s_cnt[t] = 0u;
+    __syncthreads();
+    if (has)
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(&s_cnt[(y - by0) * bw + (x - bx0)], 1u);
+    __syncthreads();
+    for (int t = tid; t < area; t += GSR_BIN_THREADS) {
+        const uint32_t c = s_cnt[t];
+        if (c) {
+            const int ty = t / bw, tx = t - ty * bw;
+            const uint32_t base = reserve((by0 + ty) * bx + bx0 + tx, c);
+            if (EMIT) { s_base[t] = base; s_cnt[t] = 0u; }
+        }
+    }
+    if (!EMIT) return;
+    __syncthreads();
+    if (has)
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const int t = (y - by0) * bw + (x - bx0);
+                emit(s_base[t] + atomicAdd(&s_cnt[t], 1u));
+            }
+}
+#endif
+
 // Launchers implemented in the .hip files (host side).  All enqueue on `s` and never synchronise.
 struct GsrFwdParams {
-    int P, W, H, gx, gy;
+    int P, W, H, gx, gy, bx, by, bx_real;
     const float *means3D, *colors, *opacities, *scales, *rotations;
     float scale_modifier, tanfovx, tanfovy;
     const float *view, *proj, *bg;
     float *out_color;
     int *radii;
     int64_t cap;
+    unsigned dbg;  // development-only switches (flags >> 8): 1 = skip bin counting, 2 = skip splat stores
 };
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *tile_count, GsrHeader *hdr, hipStream_t s);
-void gsr_launch_scan(uint32_t *tile_count, uint32_t *tile_offset, uint32_t *tile_cursor, int T, int64_t cap, GsrHeader *hdr, hipStream_t s);
-void gsr_launch_scatter(int P, int gx, const GsrSplat *splats, uint32_t *tile_cursor, uint64_t *keys, int64_t cap, const GsrHeader *hdr, hipStream_t s);
-void gsr_launch_sort(int T, const uint32_t *tile_offset, uint64_t *keys, uint32_t *point_list, const GsrHeader *hdr, hipStream_t s);
-void gsr_launch_composite_fwd(int W, int H, int gx, int gy, const GsrSplat *splats, const uint32_t *tile_offset, const uint32_t *point_list,
-                              const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
-void gsr_launch_composite_bwd(int W, int H, int gx, int gy, const GsrSplat *splats, const uint32_t *tile_offset, const uint32_t *point_list,
-                              const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib, GsrGradAcc *gacc,
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s);
+void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
+                     int64_t cap, GsrHeader *hdr, hipStream_t s);
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s);
+void gsr_launch_sort(int NB, const uint32_t *bin_offset, uint64_t *keys, uint32_t *point_list, const GsrHeader *hdr, hipStream_t s);
+void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                              const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
+void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                              const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib, GsrGradAcc *gacc,
                               const GsrHeader *hdr, hipStream_t s);
 struct GsrBwdParams {
     int P, W, H;

@@ -1,65 +1,97 @@
-// gsr_composite.hip -- forward and backward alpha compositing for gfx950 (one 256-thread workgroup per 16x16 tile).
+// gsr_composite.hip -- forward and backward alpha compositing for gfx950: ONE wave64 per 8x8-pixel bin.
 //
 // Semantics: SURVEY.md section 9.2 (front-to-back blend with the power>0 / alpha<1/255 / T<1e-4 rules) and section 9.3 (back-to-
 // front gradient recurrence); replaces upstream renderCUDA forward/backward (called through
 // /root/reference/gaussian_renderer/__init__.py:54-62 and its autograd backward).
 //
 // CDNA4 mapping:
-//   * 4 wave64 per tile; each wave owns a compact 8x8 pixel block (lane = 8x8 raster), so a splat of a few pixels
-//     radius is skipped by whole waves (s_cbranch_execz) instead of by scattered lanes;
-//   * every round stages 256 splat records {x,y,A,B | C,op,r,g | b} -- colour included -- into LDS with one 48-byte
-//     gather per thread; the inner loop then reads wave-uniform LDS addresses (broadcast, conflict free);
+//   * lane = pixel of an 8x8 bin; a 256-thread workgroup is 4 INDEPENDENT waves covering a 32x8 strip (so the four
+//     waves' 32-byte row segments complete full 128-byte lines in the XCD's L2).  There is no __syncthreads anywhere:
+//     a wave that finishes early (all pixels saturated) stops fetching immediately;
+//   * per round a wave stages 64 splat records {x,y,A,B | C,op,r,g | b} -- colour included -- with one 48-byte gather
+//     per lane into its private LDS slice; the gather for round i+1 is issued BEFORE round i is consumed (registers),
+//     so HBM/L2 latency hides under the blend loop; the blend loop reads wave-uniform LDS addresses (broadcast);
+//   * lists are exact-extent culled per bin (gsr_common.h), so a wave never iterates a splat that cannot touch it;
 //   * backward: per-(pixel, splat) gradient terms are summed across the wave with DPP row/bank shifts
-//     (v_add_f32 dpp, no LDS traffic), accumulated per staged splat in LDS by one lane per wave, and flushed with
-//     ONE global atomic per gradient component per (tile, splat) -- upstream issues one per (pixel, splat).
+//     (v_add_f32 dpp, no LDS traffic), parked per staged splat in LDS by lane 63 and flushed once per round with ONE
+//     global atomic per gradient component per (bin, splat) -- upstream issues one per (pixel, splat).
 #include "gsr_common.h"
 
 namespace {
 
-constexpr int BATCH = 256;
+constexpr int WAVE = 64;
+constexpr int WAVES = GSR_BINS_PER_WG;  // 4
 
-__device__ __forceinline__ void tile_pixel(int tid, int &lx, int &ly) {
-    const int w = tid >> 6, lane = tid & 63;
-    lx = ((w & 1) << 3) | (lane & 7);
-    ly = ((w >> 1) << 3) | (lane >> 3);
+struct WaveGeom {
+    int bin, px, py, lane, wid;
+    bool inside;
+    uint32_t r0, r1;
+};
+
+__device__ __forceinline__ WaveGeom wave_geom(int W, int H, int bx, const uint32_t *__restrict__ bin_offset,
+                                              const uint32_t *__restrict__ wg_order) {
+    WaveGeom g;
+    const int tid = threadIdx.x;
+    g.lane = tid & 63;
+    g.wid = tid >> 6;
+    const int wg = (int)wg_order[blockIdx.x];  // work-ordered dispatch: workgroups with non-empty lists come first
+    const int wgs_per_row = bx / WAVES;
+    const int by_i = wg / wgs_per_row, bx_i = (wg - by_i * wgs_per_row) * WAVES + g.wid;
+    g.bin = by_i * bx + bx_i;
+    g.px = bx_i * GSR_BIN + (g.lane & 7);
+    g.py = by_i * GSR_BIN + (g.lane >> 3);
+    g.inside = g.px < W && g.py < H;
+    g.r0 = bin_offset[g.bin];
+    g.r1 = bin_offset[g.bin + 1];
+    return g;
 }
 
-__global__ __launch_bounds__(256) void k_composite_fwd(int W, int H, int gx, const GsrSplat *__restrict__ splats,
-                                                       const uint32_t *__restrict__ tile_offset,
+__device__ __forceinline__ void wave_sync_lds() {
+    // same-wave LDS hand-off: the DS queue is in order per wave, this only pins the compiler's ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void k_composite_fwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+                                                       const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        float *__restrict__ out_color, float *__restrict__ final_T,
                                                        uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr) {
-    __shared__ float4 sA[BATCH];
-    __shared__ float4 sB[BATCH];
-    __shared__ float sC[BATCH];
+    __shared__ float4 sA[WAVES][WAVE];
+    __shared__ float4 sB[WAVES][WAVE];
+    __shared__ float sC[WAVES][WAVE];
     if (hdr->overflow) return;
-    const int tile = blockIdx.x, tid = threadIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
-    int lx, ly;
-    tile_pixel(tid, lx, ly);
-    const int px = tx * GSR_TILE + lx, py = ty * GSR_TILE + ly;
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint32_t r0 = tile_offset[tile], r1 = tile_offset[tile + 1];
+    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order);
+    const float pxf = (float)g.px, pyf = (float)g.py;
+    float4 *wA = sA[g.wid], *wB = sB[g.wid];
+    float *wC = sC[g.wid];
 
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t contributor = 0, last = 0;
-    bool done = !inside;
-    for (uint32_t base = r0; base < r1; base += BATCH) {
-        if (__syncthreads_count(done) == BATCH) break;
-        const uint32_t k = base + tid;
-        if (k < r1) {
-            const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[k]);
-            sA[tid] = s[0];
-            sB[tid] = s[1];
-            sC[tid] = s[2].x;
+    bool done = !g.inside;
+
+    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
+    float nC = 0.f;
+    if (g.r0 + g.lane < g.r1) {  // prefetch round 0
+        const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[g.r0 + g.lane]);
+        nA = s[0]; nB = s[1]; nC = s[2].x;
+    }
+    for (uint32_t base = g.r0; base < g.r1; base += WAVE) {
+        if (__ballot(!done) == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
+        wave_sync_lds();                     // previous round fully consumed
+        wA[g.lane] = nA; wB[g.lane] = nB; wC[g.lane] = nC;
+        wave_sync_lds();
+        const uint32_t nk = base + WAVE + g.lane;
+        if (nk < g.r1) {  // prefetch the next round while this one is blended
+            const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[nk]);
+            nA = s[0]; nB = s[1]; nC = s[2].x;
         }
-        __syncthreads();
-        const int cnt = (int)min((uint32_t)BATCH, r1 - base);
+        const int cnt = (int)min((uint32_t)WAVE, g.r1 - base);
         for (int j = 0; !done && j < cnt; j++) {
             contributor++;
-            const float4 a = sA[j];
-            const float4 b = sB[j];
+            const float4 a = wA[j];
+            const float4 b = wB[j];
             const float dx = a.x - pxf, dy = a.y - pyf;
             const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
             if (power > 0.f) continue;
@@ -73,13 +105,13 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int W, int H, int gx, con
             const float w = alpha * T;
             C0 += b.z * w;
             C1 += b.w * w;
-            C2 += sC[j] * w;
+            C2 += wC[j] * w;
             T = test_T;
             last = contributor;
         }
     }
-    if (inside) {
-        const size_t npix = (size_t)W * H, q = (size_t)py * W + px;
+    if (g.inside) {
+        const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
         final_T[q] = T;
         n_contrib[q] = last;
         out_color[q] = C0 + T * bg[0];
@@ -88,50 +120,63 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int W, int H, int gx, con
     }
 }
 
-// ---- wave64 sum via DPP; result valid in lane 63 -----------------------------------------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
+// ---- nine simultaneous wave64 sums via DPP; results valid in lane 63 ---------------------------------------------------
+// Steps 1-4 (inside a 16-lane row) go through the builtin, which the compiler folds into v_add_f32_dpp.  The two
+// cross-row steps need "unwritten rows keep their value" semantics (row_mask), which the builtin form cannot fold, so
+// they are written as in-place v_add_f32_dpp.  The nine chains are interleaved: every DPP read is >= 9 instructions
+// behind the write it depends on, so only the first instruction needs the 2-wait-state pad (s_nop 1) after compiler code.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_row(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
     return v + __int_as_float(t);
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<0xB1, 0xF, 0xF>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xF, 0xF>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x114, 0xF, 0xF>(v);  // row_shr:4
-    v = dpp_add<0x118, 0xF, 0xF>(v);  // row_shr:8   -> lanes 12..15 of each row hold the row sum
-    v = dpp_add<0x142, 0xA, 0xF>(v);  // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xC, 0xF>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = wave sum
-    return v;
+__device__ __forceinline__ void wave_sum9_to_lane63(float (&v)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0xB1>(v[k]);  // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0x4E>(v[k]);  // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0x114>(v[k]); // row_shr:4
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0x118>(v[k]); // row_shr:8 -> lanes 12..15 of each row hold the row sum
+#define GSR_BC(n, ctl) "v_add_f32_dpp %" #n ", %" #n ", %" #n " " ctl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 GSR_BC(0, "row_bcast:15 row_mask:0xa") GSR_BC(1, "row_bcast:15 row_mask:0xa") GSR_BC(2, "row_bcast:15 row_mask:0xa")
+                 GSR_BC(3, "row_bcast:15 row_mask:0xa") GSR_BC(4, "row_bcast:15 row_mask:0xa") GSR_BC(5, "row_bcast:15 row_mask:0xa")
+                 GSR_BC(6, "row_bcast:15 row_mask:0xa") GSR_BC(7, "row_bcast:15 row_mask:0xa") GSR_BC(8, "row_bcast:15 row_mask:0xa")
+                 GSR_BC(0, "row_bcast:31 row_mask:0xc") GSR_BC(1, "row_bcast:31 row_mask:0xc") GSR_BC(2, "row_bcast:31 row_mask:0xc")
+                 GSR_BC(3, "row_bcast:31 row_mask:0xc") GSR_BC(4, "row_bcast:31 row_mask:0xc") GSR_BC(5, "row_bcast:31 row_mask:0xc")
+                 GSR_BC(6, "row_bcast:31 row_mask:0xc") GSR_BC(7, "row_bcast:31 row_mask:0xc") GSR_BC(8, "row_bcast:31 row_mask:0xc")
+                 "s_nop 0"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+#undef GSR_BC
 }
 
-__global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int gx, const GsrSplat *__restrict__ splats,
-                                                       const uint32_t *__restrict__ tile_offset,
+__global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+                                                       const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
                                                        const uint32_t *__restrict__ n_contrib, GsrGradAcc *__restrict__ gacc,
                                                        const GsrHeader *__restrict__ hdr) {
-    __shared__ float4 sA[BATCH];
-    __shared__ float4 sB[BATCH];
-    __shared__ float sC[BATCH];
-    __shared__ uint32_t sId[BATCH];
-    __shared__ float sAcc[BATCH * 9];
-    __shared__ uint32_t sMax[4];
-    if (hdr->overflow) return;
-    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tx = tile % gx, ty = tile / gx;
-    const uint32_t r0 = tile_offset[tile], r1 = tile_offset[tile + 1];
-    if (r1 <= r0) return;
-    int lx, ly;
-    tile_pixel(tid, lx, ly);
-    const int px = tx * GSR_TILE + lx, py = ty * GSR_TILE + ly;
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const size_t npix = (size_t)W * H, q = (size_t)py * W + px;
+    __shared__ float4 sA[WAVES][WAVE];
+    __shared__ float4 sB[WAVES][WAVE];
+    __shared__ float sC[WAVES][WAVE];
+    __shared__ uint32_t sId[WAVES][WAVE];
+    __shared__ float4 sAcc[WAVES][WAVE * 3];  // per staged splat: {dr,dg,db,dmx | dmy,cxx,cxy,cyy | dop,-,-,-}
+    if (hdr->overflow || blockIdx.x >= hdr->num_busy_wgs) return;  // idle workgroups sit at the end of wg_order
+    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order);
+    if (g.r1 <= g.r0) return;
+    const int lane = g.lane;
+    const float pxf = (float)g.px, pyf = (float)g.py;
+    const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
+    float4 *wA = sA[g.wid], *wB = sB[g.wid], *wAcc = sAcc[g.wid];
+    float *wC = sC[g.wid];
+    uint32_t *wId = sId[g.wid];
 
-    const float T_final = inside ? final_T[q] : 0.f;
-    const uint32_t last = inside ? n_contrib[q] : 0u;
+    const float T_final = g.inside ? final_T[q] : 0.f;
+    const uint32_t last = g.inside ? n_contrib[q] : 0u;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    if (inside) {
+    if (g.inside) {
         d0 = dL_dpix[q];
         d1 = dL_dpix[npix + q];
         d2 = dL_dpix[2 * npix + q];
@@ -139,48 +184,54 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int gx, con
     const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
-    // deepest contributor over the tile: nothing behind it receives gradient
+    // deepest contributor over the bin: nothing behind it receives gradient
     uint32_t m = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-    if (lane == 0) sMax[wid] = m;
-    __syncthreads();
-    const uint32_t max_last = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+    const int64_t max_last = (int64_t)__builtin_amdgcn_readfirstlane((int)m);
+    if (max_last == 0) return;
 
     float T = T_final, ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
 
-    // positions are 0-based from the front of the tile list; walk from max_last-1 down to 0 in rounds of 256
-    for (int64_t top = (int64_t)max_last - 1; top >= 0; top -= BATCH) {
-        __syncthreads();  // previous round's flush has finished with sAcc / sId
-        const int cnt = (int)min((int64_t)BATCH, top + 1);
-        if (tid < cnt) {
-            const uint32_t id = point_list[r0 + (uint32_t)(top - tid)];
-            const float4 *s = reinterpret_cast<const float4 *>(splats + id);
-            sA[tid] = s[0];
-            sB[tid] = s[1];
-            sC[tid] = s[2].x;
-            sId[tid] = id;
+    // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64
+    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
+    float nC = 0.f;
+    uint32_t nId = 0;
+    if ((int64_t)lane <= max_last - 1) {
+        nId = point_list[g.r0 + (uint32_t)(max_last - 1 - lane)];
+        const float4 *s = reinterpret_cast<const float4 *>(splats + nId);
+        nA = s[0]; nB = s[1]; nC = s[2].x;
+    }
+    for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
+        const int cnt = (int)min((int64_t)WAVE, top + 1);
+        wave_sync_lds();
+        wA[lane] = nA; wB[lane] = nB; wC[lane] = nC; wId[lane] = nId;
+        wave_sync_lds();
+        const int64_t ntop = top - WAVE;
+        if (ntop - lane >= 0) {  // prefetch the next round
+            nId = point_list[g.r0 + (uint32_t)(ntop - lane)];
+            const float4 *s = reinterpret_cast<const float4 *>(splats + nId);
+            nA = s[0]; nB = s[1]; nC = s[2].x;
         }
-#pragma unroll
-        for (int k = 0; k < 9; k++) sAcc[tid * 9 + k] = 0.f;
-        __syncthreads();
+        unsigned long long touched = 0ull;  // which staged splats received any gradient (wave-uniform)
         for (int j = 0; j < cnt; j++) {
             const uint32_t pos = (uint32_t)(top - j);
-            const float4 a = sA[j];
-            const float4 b = sB[j];
+            const float4 a = wA[j];
+            const float4 b = wB[j];
             const float dx = a.x - pxf, dy = a.y - pyf;
             const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
             const float G = __expf(power);
             const float alpha = fminf(0.99f, b.y * G);
             const bool valid = (pos < last) && !(power > 0.f) && !(alpha < 1.f / 255.f);
             if (!__any(valid)) continue;  // wave-uniform
+            touched |= 1ull << j;
 
             float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f;
             if (valid) {
                 const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = T * rcp;
                 const float dchannel_dcolor = alpha * T;
-                const float c0 = b.z, c1 = b.w, c2 = sC[j];
+                const float c0 = b.z, c1 = b.w, c2 = wC[j];
                 ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
                 ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
                 ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
@@ -203,49 +254,42 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int gx, con
                 g_yy = -0.5f * gdy * dy * dL_dG;
                 g_op = G * dL_dalpha;
             }
-            g_r = wave_sum_to_lane63(g_r);
-            g_g = wave_sum_to_lane63(g_g);
-            g_b = wave_sum_to_lane63(g_b);
-            g_mx = wave_sum_to_lane63(g_mx);
-            g_my = wave_sum_to_lane63(g_my);
-            g_xx = wave_sum_to_lane63(g_xx);
-            g_xy = wave_sum_to_lane63(g_xy);
-            g_yy = wave_sum_to_lane63(g_yy);
-            g_op = wave_sum_to_lane63(g_op);
+            float red[9] = {g_r, g_g, g_b, g_mx, g_my, g_xx, g_xy, g_yy, g_op};
+            wave_sum9_to_lane63(red);
             if (lane == 63) {
-                float *acc = sAcc + j * 9;
-                atomicAdd(acc + 0, g_r); atomicAdd(acc + 1, g_g); atomicAdd(acc + 2, g_b);
-                atomicAdd(acc + 3, g_mx); atomicAdd(acc + 4, g_my);
-                atomicAdd(acc + 5, g_xx); atomicAdd(acc + 6, g_xy); atomicAdd(acc + 7, g_yy);
-                atomicAdd(acc + 8, g_op);
+                wAcc[3 * j + 0] = make_float4(red[0], red[1], red[2], red[3]);
+                wAcc[3 * j + 1] = make_float4(red[4], red[5], red[6], red[7]);
+                wAcc[3 * j + 2] = make_float4(red[8], 0.f, 0.f, 0.f);
             }
         }
-        __syncthreads();
-        if (tid < cnt) {
-            const float *acc = sAcc + tid * 9;
-            float *dst = reinterpret_cast<float *>(gacc + sId[tid]);
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const float v = acc[k];
-                if (v != 0.f) atomicAdd(dst + k, v);
-            }
+        wave_sync_lds();
+        if ((touched >> lane) & 1ull) {  // lane j flushes staged splat j: 9 atomics per (bin, splat)
+            const float4 v0 = wAcc[3 * lane], v1 = wAcc[3 * lane + 1];
+            const float v2 = wAcc[3 * lane + 2].x;
+            float *dst = reinterpret_cast<float *>(gacc + wId[lane]);
+            atomicAdd(dst + 0, v0.x); atomicAdd(dst + 1, v0.y); atomicAdd(dst + 2, v0.z); atomicAdd(dst + 3, v0.w);
+            atomicAdd(dst + 4, v1.x); atomicAdd(dst + 5, v1.y); atomicAdd(dst + 6, v1.z); atomicAdd(dst + 7, v1.w);
+            atomicAdd(dst + 8, v2);
         }
     }
 }
 
 }  // namespace
 
-void gsr_launch_composite_fwd(int W, int H, int gx, int gy, const GsrSplat *splats, const uint32_t *tile_offset, const uint32_t *point_list,
-                              const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s) {
-    if (gx * gy <= 0) return;
-    hipLaunchKernelGGL(k_composite_fwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, splats, tile_offset, point_list, bg, out_color, final_T,
-                       n_contrib, hdr);
+void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                              const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
+                              const GsrHeader *hdr, hipStream_t s) {
+    const int wgs = (bx / WAVES) * by;
+    if (wgs <= 0) return;
+    hipLaunchKernelGGL(k_composite_fwd, dim3(wgs), dim3(256), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
+                       final_T, n_contrib, hdr);
 }
 
-void gsr_launch_composite_bwd(int W, int H, int gx, int gy, const GsrSplat *splats, const uint32_t *tile_offset, const uint32_t *point_list,
-                              const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib, GsrGradAcc *gacc,
-                              const GsrHeader *hdr, hipStream_t s) {
-    if (gx * gy <= 0) return;
-    hipLaunchKernelGGL(k_composite_bwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, splats, tile_offset, point_list, bg, dL_dpix, final_T,
-                       n_contrib, gacc, hdr);
+void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                              const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
+                              const uint32_t *n_contrib, GsrGradAcc *gacc, const GsrHeader *hdr, hipStream_t s) {
+    const int wgs = (bx / WAVES) * by;
+    if (wgs <= 0) return;
+    hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(256), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
+                       final_T, n_contrib, gacc, hdr);
 }

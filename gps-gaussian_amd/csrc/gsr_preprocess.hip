@@ -88,10 +88,11 @@ __device__ __forceinline__ void cov2d(const Ewa &e, const float c6[6], float &a,
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(256) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats,
-                                                    uint32_t *__restrict__ tile_count, GsrHeader *__restrict__ hdr) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= q.P) return;
+__global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats,
+                                                               uint32_t *__restrict__ bin_count, GsrHeader *__restrict__ hdr) {
+    const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
+    uint32_t rlo = 0, rhi = 0;
+    if (i < q.P) {
     const Cam cam = load_cam(q.view, q.proj);
     const float p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
     const float col[3] = {q.colors[3 * (size_t)i], q.colors[3 * (size_t)i + 1], q.colors[3 * (size_t)i + 2]};
@@ -99,7 +100,6 @@ __global__ __launch_bounds__(256) void k_preprocess(GsrFwdParams q, GsrSplat *__
 
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = make_float4(0.f, op, col[0], col[1]);
     float o2x = col[2], o2y = 0.f;
-    uint32_t rlo = 0, rhi = 0;
     int radius = 0;
 
     float pv[3];
@@ -142,10 +142,23 @@ __global__ __launch_bounds__(256) void k_preprocess(GsrFwdParams q, GsrSplat *__
                 o0 = make_float4(px, py, c * det_inv, -b * det_inv);
                 o1.x = a * det_inv;
                 o2y = pv[2];
-                rlo = (uint32_t)r0x | ((uint32_t)r0y << 16);
-                rhi = (uint32_t)r1x | ((uint32_t)r1y << 16);
-                for (int ty = r0y; ty < r1y; ty++)
-                    for (int tx = r0x; tx < r1x; tx++) atomicAdd(&tile_count[ty * q.gx + tx], 1u);
+                // Bin rect = (upstream's 16x16-tile rect, in 8-px bins) INTERSECT (bounding box of the alpha >= 1/255
+                // level set).  alpha = op * exp(power) >= 1/255  <=>  d^T Sigma^-1 d <= 2 ln(255 op) =: 2 tau, whose
+                // axis-aligned extent is |dx| <= sqrt(2 tau a), |dy| <= sqrt(2 tau c) with (a,b,c) the dilated 2D
+                // covariance.  Pairs outside can never pass the alpha test, so not listing them is exact; the box is
+                // inflated a little so that fp32 rounding in the compositing kernels can never disagree with it.
+                const float tau = logf(255.f * op);
+                if (tau >= 0.f) {
+                    const float hx = sqrtf(2.f * tau * a) * 1.001f + 0.01f, hy = sqrtf(2.f * tau * c) * 1.001f + 0.01f;
+                    int b0x = (int)floorf((px - hx) / 8.f), b1x = (int)floorf((px + hx) / 8.f) + 1;
+                    int b0y = (int)floorf((py - hy) / 8.f), b1y = (int)floorf((py + hy) / 8.f) + 1;
+                    b0x = max(b0x, 2 * r0x); b1x = min(b1x, min(2 * r1x, q.bx_real));
+                    b0y = max(b0y, 2 * r0y); b1y = min(b1y, min(2 * r1y, q.by));
+                    if (b1x > b0x && b1y > b0y) {
+                        rlo = (uint32_t)b0x | ((uint32_t)b0y << 16);
+                        rhi = (uint32_t)b1x | ((uint32_t)b1y << 16);
+                    }
+                }
             }
         }
     }
@@ -154,6 +167,9 @@ __global__ __launch_bounds__(256) void k_preprocess(GsrFwdParams q, GsrSplat *__
     dst[1] = o1;
     dst[2] = make_float4(o2x, o2y, __uint_as_float(rlo), __uint_as_float(rhi));
     q.radii[i] = radius;
+    }
+    gsr_block_bin<false>(
+        rlo, rhi, q.bx, [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {});
 }
 
 __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrGradAcc *__restrict__ gacc) {
@@ -268,9 +284,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
 
 }  // namespace
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *tile_count, GsrHeader *hdr, hipStream_t s) {
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, tile_count, hdr);
+    hipLaunchKernelGGL(k_preprocess, dim3((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, p, splats, bin_count, hdr);
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrGradAcc *gacc, hipStream_t s) {

@@ -251,15 +251,16 @@ def last_stats(device=None):
 
 
 def export_state(ws, P, W, H, cap):
-    """Debug/parity helper: unpack a forward's workspace into tensors (depth, xy, conic_opacity, rect, ranges, ...)."""
+    """Debug/parity helper: unpack a forward's workspace into tensors: depth, xy, conic_opacity, rect (the 8x8-BIN rect
+    bx0,by0,bx1,by1 each Gaussian is listed in), ranges [bx*by, 2] (per-bin list range), point_list, final_T, n_contrib."""
     lib = _capi.lib()
     dev = ws.device
     hdr = ws[:16].view(torch.int64).cpu()
     R = int(hdr[0])
-    gx, gy = (W + 15) // 16, (H + 15) // 16
+    bx, by = ((W + 7) // 8 + 3) // 4 * 4, (H + 7) // 8   # padded bin grid (gsr_common.h)
     out = dict(
         depth=torch.empty(P, device=dev), xy=torch.empty(P, 2, device=dev), conic_opacity=torch.empty(P, 4, device=dev),
-        rect=torch.empty(P, 4, dtype=torch.int32, device=dev), ranges=torch.empty(gx * gy, 2, dtype=torch.int64, device=dev),
+        rect=torch.empty(P, 4, dtype=torch.int32, device=dev), ranges=torch.empty(bx * by, 2, dtype=torch.int64, device=dev),
         point_list=torch.empty(max(cap, 1), dtype=torch.int32, device=dev), final_T=torch.empty(H, W, device=dev),
         n_contrib=torch.empty(H, W, dtype=torch.int32, device=dev))
     with torch.cuda.device(dev):
@@ -270,5 +271,6 @@ def export_state(ws, P, W, H, cap):
     torch.cuda.synchronize(dev)
     out["point_list"] = out["point_list"][:R]
     out["num_rendered"] = R
+    out["bx"], out["by"] = bx, by
     out["overflow"] = int(hdr[1]) & 0xffffffff
     return out

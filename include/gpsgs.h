@@ -57,7 +57,7 @@ const char *gpsgs_build_info(void); /* "gfx950 <compiler> <date>" */
 /* ---- rasteriser ---------------------------------------------------------------------------------------------
  * Workspace: one caller-owned device buffer (>= gsr_workspace_bytes, 256-byte aligned) that carries the forward's
  * state to the backward (what upstream keeps in geomBuffer / binningBuffer / imgBuffer).
- * `instance_capacity` bounds R = number of (Gaussian, tile) instances the buffer can bin.  R is data dependent; the
+ * `instance_capacity` bounds R = number of (Gaussian, 8x8-pixel bin) instances the buffer can hold.  R is data dependent; the
  * forward never reads it back.  Instead the header records the R that was needed and an overflow flag:
  *   - overflow == 0: results are exact;
  *   - overflow != 0: NOTHING was rendered (out_color untouched apart from zero fill); the caller must re-run with
@@ -66,8 +66,8 @@ const char *gpsgs_build_info(void); /* "gfx950 <compiler> <date>" */
 typedef struct GsrHeader {      /* first bytes of the workspace, device memory */
     uint64_t num_rendered;      /* R needed by the last gsr_forward */
     uint32_t overflow;          /* 1 if R > instance_capacity */
-    uint32_t max_tile_count;    /* longest per-tile list */
-    uint32_t num_visible;       /* Gaussians with radius > 0 */
+    uint32_t max_tile_count;    /* longest per-bin list (one 8x8-pixel bin = one wave64 work item) */
+    uint32_t num_busy_wgs;      /* compositing workgroups (4 bins each) with a non-empty list; they are scheduled first */
     uint32_t reserved[11];
 } GsrHeader;
 
@@ -100,8 +100,9 @@ int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream);
 int gsr_timing_read(float *ms_sum_host, int *launches_host);
 
 /* Debug/parity helper: copies selected intermediate arrays out of the workspace into caller DEVICE buffers (any may
- * be NULL): depth[P], xy[P,2], conic_opacity[P,4], rect[P,4] (int32 minx,miny,maxx,maxy), tile_ranges[T,2] (int64),
- * point_list[num_rendered] (uint32, sorted), final_T[H,W], n_contrib[H,W]. */
+ * be NULL): depth[P], xy[P,2], conic_opacity[P,4], rect[P,4] (int32 bx0,by0,bx1,by1: the 8x8-pixel BIN rect the Gaussian
+ * is listed in), tile_ranges[NB,2] (int64 list range per bin; NB = (ceil(W/8) rounded up to 4) * ceil(H/8)),
+ * point_list[num_rendered] (uint32, sorted per bin), final_T[H,W], n_contrib[H,W]. */
 int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, float *depth,
                      float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges, uint32_t *point_list,
                      float *final_T, uint32_t *n_contrib, void *stream);
