@@ -73,6 +73,11 @@ extern "C" size_t gsr_workspace_bytes(int P, int width, int height, int64_t inst
     return gsr_layout(P, width, height, instance_capacity).total;
 }
 
+extern "C" size_t gsr_workspace_bytes_forward_only(int P, int width, int height, int64_t instance_capacity) {
+    if (P < 0 || width < 0 || height < 0 || instance_capacity < 0) return 0;
+    return gsr_layout(P, width, height, instance_capacity).total_fwd;
+}
+
 extern "C" int gsr_forward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
                            const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
                            const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
@@ -83,7 +88,7 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     if (P > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !projmatrix || !bg || !radii))
         return GPSGS_E_INVALID;
     const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
-    if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
+    if (workspace_bytes < L.total_fwd) return GPSGS_E_WORKSPACE;  // the backward tail is optional for a forward
     hipStream_t s = (hipStream_t)stream;
     GsrHeader *hdr = reinterpret_cast<GsrHeader *>(at(workspace, L.header));
     uint32_t *bin_count = reinterpret_cast<uint32_t *>(at(workspace, L.bin_count));
@@ -160,13 +165,19 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     const uint32_t *point_list = reinterpret_cast<const uint32_t *>(at(workspace, L.point_list));
     const float *final_T = reinterpret_cast<const float *>(at(workspace, L.final_T));
     const uint32_t *n_contrib = reinterpret_cast<const uint32_t *>(at(workspace, L.n_contrib));
-    GsrGradAcc *gacc = reinterpret_cast<GsrGradAcc *>(at(workspace, L.gacc));
+    uint32_t *goff = reinterpret_cast<uint32_t *>(at(workspace, L.goff));
+    uint32_t *gscan_part = reinterpret_cast<uint32_t *>(at(workspace, L.gscan_part));
+    uint32_t *inst_pos = reinterpret_cast<uint32_t *>(at(workspace, L.inst_pos));
+    GsrGradAcc *inst_grad = reinterpret_cast<GsrGradAcc *>(at(workspace, L.inst_grad));
 
-    if (hipMemsetAsync(gacc, 0, (size_t)P * sizeof(GsrGradAcc), s) != hipSuccess) return GPSGS_E_LAUNCH;
+    // inst_pos = ~0 ("no record"): only instances the compositing backward actually reaches get a record
+    if (hipMemsetAsync(inst_pos, 0xff, (size_t)(instance_capacity > 0 ? instance_capacity : 1) * 4, s) != hipSuccess) return GPSGS_E_LAUNCH;
+    gsr_launch_gauss_scan(P, splats, goff, gscan_part, s);
     int rc;
+    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_COMPOSITE_BWD, s);
-        gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, gacc, hdr, s);
+        gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, inst_pos, inst_grad, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     GsrBwdParams b;
@@ -178,7 +189,7 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
     {
         StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);
-        gsr_launch_preprocess_bwd(b, gacc, s);
+        gsr_launch_preprocess_bwd(b, splats, goff, inst_pos, inst_grad, s);
     }
     return check(s, flags);
 }

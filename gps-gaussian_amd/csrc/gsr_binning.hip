@@ -49,9 +49,7 @@ __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x * SB + tid;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
-    const unsigned long long nz = __ballot(c > 0);
-    // workgroup w = bins 4w..4w+3 = 4 consecutive lanes; counted once by its first lane
-    const uint32_t busy = ((lane & 3) == 0 && ((nz >> lane) & 0xFull)) ? 1u : 0u;
+    const uint32_t busy = c > 0 ? 1u : 0u;  // one compositing workgroup (= one wave) per bin
     uint32_t s = c, nb = busy, mx = c;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -75,7 +73,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
                                                uint32_t *__restrict__ wg_order, int NB, int nblocks, int64_t cap,
                                                GsrHeader *__restrict__ hdr) {
     __shared__ uint32_t wsum[SB / 64];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     uint32_t pre_sum = 0, pre_busy = 0, tot_sum = 0, tot_busy = 0, tot_max = 0;
     for (int i = 0; i < nblocks; i++) {  // wave-uniform loads of a handful of uint4
         const uint4 p = part[i];
@@ -91,9 +89,8 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         bin_cursor[(size_t)b * GSR_CPAD] = off;
     }
     // work-ordered workgroup list
-    const unsigned long long nz = __ballot(c > 0);
-    const bool is_wg_lead = (lane & 3) == 0 && b < NB;
-    const bool busy = is_wg_lead && ((nz >> lane) & 0xFull);
+    const bool is_wg_lead = b < NB;
+    const bool busy = is_wg_lead && c > 0;
     uint32_t blk_busy;
     const uint32_t bpos = block_exscan(busy ? 1u : 0u, wsum, &blk_busy);
     if (is_wg_lead) {

@@ -5,16 +5,19 @@
 // /root/reference/gaussian_renderer/__init__.py:54-62 and its autograd backward).
 //
 // CDNA4 mapping:
-//   * lane = pixel of an 8x8 bin; a 256-thread workgroup is 4 INDEPENDENT waves covering a 32x8 strip (so the four
-//     waves' 32-byte row segments complete full 128-byte lines in the XCD's L2).  There is no __syncthreads anywhere:
-//     a wave that finishes early (all pixels saturated) stops fetching immediately;
+//   * lane = pixel of an 8x8 bin; every workgroup is ONE wave, so the dispatcher balances the CUs at wave granularity
+//     (4-wave workgroups packed greedily left CUs with 7 busy workgroups next to CUs with 4).  There is no
+//     __syncthreads anywhere: a wave that finishes early (all pixels saturated) stops fetching immediately;
 //   * per round a wave stages 64 splat records {x,y,A,B | C,op,r,g | b} -- colour included -- with one 48-byte gather
 //     per lane into its private LDS slice; the gather for round i+1 is issued BEFORE round i is consumed (registers),
 //     so HBM/L2 latency hides under the blend loop; the blend loop reads wave-uniform LDS addresses (broadcast);
 //   * lists are exact-extent culled per bin (gsr_common.h), so a wave never iterates a splat that cannot touch it;
-//   * backward: per-(pixel, splat) gradient terms are summed across the wave with DPP row/bank shifts
-//     (v_add_f32 dpp, no LDS traffic), parked per staged splat in LDS by lane 63 and flushed once per round with ONE
-//     global atomic per gradient component per (bin, splat) -- upstream issues one per (pixel, splat).
+//   * backward: the 9 per-(pixel, splat) gradient terms are summed across the wave with a butterfly reduce-scatter
+//     (v_permlane32/16_swap + DPP, 22 instructions instead of 54, no LDS traffic), parked per staged splat in LDS by
+//     12 lanes and flushed once per round as 48-byte per-INSTANCE records with plain coalesced stores.  There is no
+//     global atomic in the backward at all (upstream issues 10 per (pixel, splat); float atomics run at only
+//     20-30 Mops/ms on MI355X): k_preprocess_bwd gathers each Gaussian's few instance records in a fixed order, so
+//     gradients are also bit-reproducible.
 #include "gsr_common.h"
 
 namespace {
@@ -53,7 +56,7 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void k_composite_fwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+__global__ __launch_bounds__(64 * WAVES) void k_composite_fwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                        const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        float *__restrict__ out_color, float *__restrict__ final_T,
@@ -120,49 +123,68 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int W, int H, int bx, con
     }
 }
 
-// ---- nine simultaneous wave64 sums via DPP; results valid in lane 63 ---------------------------------------------------
-// Steps 1-4 (inside a 16-lane row) go through the builtin, which the compiler folds into v_add_f32_dpp.  The two
-// cross-row steps need "unwritten rows keep their value" semantics (row_mask), which the builtin form cannot fold, so
-// they are written as in-place v_add_f32_dpp.  The nine chains are interleaved: every DPP read is >= 9 instructions
-// behind the write it depends on, so only the first instruction needs the 2-wait-state pad (s_nop 1) after compiler code.
+// ---- nine simultaneous wave64 sums as a butterfly REDUCE-SCATTER ------------------------------------------------------
+// Summing 9 values over 64 lanes one by one costs 9 x 6 = 54 DPP adds.  A reduce-scatter halves the number of live
+// registers at every level instead:  xor-32 level: v_permlane32_swap + add folds TWO values into one register (lower
+// half-wave = value a, upper = value b);  xor-16 level: v_permlane16_swap + add folds two of those (even rows / odd rows);
+// xor-8 level: one select pair + row_ror:8 add;  then 3 DPP adds inside each 8-lane group.  8 values: 8+4+3+3 = 18
+// instructions; the 9th is only row-reduced (4 DPP adds) and its 4 row sums are added at flush time.
+// Result: value k of v[0..7] sits (fully summed) in every lane of one 8-lane group, see acc_slot(); v[8]'s row sums
+// sit in lanes 15, 31, 47, 63.
 template <int CTRL>
 __device__ __forceinline__ float dpp_add_row(float v) {
     const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
     return v + __int_as_float(t);
 }
-__device__ __forceinline__ void wave_sum9_to_lane63(float (&v)[9]) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0xB1>(v[k]);  // quad_perm [1,0,3,2]
-#pragma unroll
-    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0x4E>(v[k]);  // quad_perm [2,3,0,1]
-#pragma unroll
-    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0x114>(v[k]); // row_shr:4
-#pragma unroll
-    for (int k = 0; k < 9; k++) v[k] = dpp_add_row<0x118>(v[k]); // row_shr:8 -> lanes 12..15 of each row hold the row sum
-#define GSR_BC(n, ctl) "v_add_f32_dpp %" #n ", %" #n ", %" #n " " ctl "\n\t"
-    asm volatile("s_nop 1\n\t"
-                 GSR_BC(0, "row_bcast:15 row_mask:0xa") GSR_BC(1, "row_bcast:15 row_mask:0xa") GSR_BC(2, "row_bcast:15 row_mask:0xa")
-                 GSR_BC(3, "row_bcast:15 row_mask:0xa") GSR_BC(4, "row_bcast:15 row_mask:0xa") GSR_BC(5, "row_bcast:15 row_mask:0xa")
-                 GSR_BC(6, "row_bcast:15 row_mask:0xa") GSR_BC(7, "row_bcast:15 row_mask:0xa") GSR_BC(8, "row_bcast:15 row_mask:0xa")
-                 GSR_BC(0, "row_bcast:31 row_mask:0xc") GSR_BC(1, "row_bcast:31 row_mask:0xc") GSR_BC(2, "row_bcast:31 row_mask:0xc")
-                 GSR_BC(3, "row_bcast:31 row_mask:0xc") GSR_BC(4, "row_bcast:31 row_mask:0xc") GSR_BC(5, "row_bcast:31 row_mask:0xc")
-                 GSR_BC(6, "row_bcast:31 row_mask:0xc") GSR_BC(7, "row_bcast:31 row_mask:0xc") GSR_BC(8, "row_bcast:31 row_mask:0xc")
-                 "s_nop 0"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
-#undef GSR_BC
+__device__ __forceinline__ float swap_add32(float a, float b) {  // lanes 0-31: a[l]+a[l+32], lanes 32-63: b[l-32]+b[l]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {  // even rows: a folded over row pairs, odd rows: b
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// which accumulator slot (0..11) this lane writes, or -1: lanes 0,8,..,56 hold v[0..7]; lanes 15,31,47,63 the 4 row sums of v[8]
+__device__ __forceinline__ int acc_slot(int lane) {
+    if ((lane & 7) == 0) {
+        const int grp = lane >> 3;  // (row, half): row0 -> v0|v4, row1 -> v2|v6, row2 -> v1|v5, row3 -> v3|v7
+        const int row = grp >> 1, half = grp & 1;
+        const int base = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;
+        return base + 4 * half;
+    }
+    if ((lane & 15) == 15) return 8 + (lane >> 4);
+    return -1;
+}
+__device__ __forceinline__ float wave_reduce_scatter9(const float (&v)[9], bool upper8) {
+    const float u0 = swap_add32(v[0], v[1]), u1 = swap_add32(v[2], v[3]);
+    const float u2 = swap_add32(v[4], v[5]), u3 = swap_add32(v[6], v[7]);
+    const float t0 = swap_add16(u0, u1);  // rows: v0, v2, v1, v3
+    const float t1 = swap_add16(u2, u3);  // rows: v4, v6, v5, v7
+    const float keep = upper8 ? t1 : t0, send = upper8 ? t0 : t1;
+    const int sw = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xF, 0xF, true);  // row_ror:8
+    float r = keep + __int_as_float(sw);
+    r = dpp_add_row<0x141>(r);  // row_half_mirror
+    r = dpp_add_row<0x1B>(r);   // quad_perm [3,2,1,0]
+    r = dpp_add_row<0xB1>(r);   // quad_perm [1,0,3,2]  -> every lane of an 8-lane group holds its value's wave sum
+    float w = v[8];
+    w = dpp_add_row<0xB1>(w);
+    w = dpp_add_row<0x4E>(w);   // quad_perm [2,3,0,1]
+    w = dpp_add_row<0x114>(w);  // row_shr:4
+    w = dpp_add_row<0x118>(w);  // row_shr:8 -> lane 15 of each row holds the row sum
+    return ((__lane_id() & 15) == 15) ? w : r;
 }
 
-__global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+__global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                        const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
-                                                       const uint32_t *__restrict__ n_contrib, GsrGradAcc *__restrict__ gacc,
+                                                       const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
+                                                       uint32_t *__restrict__ inst_pos, GsrGradAcc *__restrict__ inst_grad,
                                                        const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sA[WAVES][WAVE];
     __shared__ float4 sB[WAVES][WAVE];
     __shared__ float sC[WAVES][WAVE];
-    __shared__ uint32_t sId[WAVES][WAVE];
-    __shared__ float4 sAcc[WAVES][WAVE * 3];  // per staged splat: {dr,dg,db,dmx | dmy,cxx,cxy,cyy | dop,-,-,-}
+    __shared__ float4 sAcc[WAVES][WAVE * 3];  // per staged splat: {dr,dg,db,dmx | dmy,cxx,cxy,cyy | 4 row sums of dop}
     if (hdr->overflow || blockIdx.x >= hdr->num_busy_wgs) return;  // idle workgroups sit at the end of wg_order
     const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order);
     if (g.r1 <= g.r0) return;
@@ -170,8 +192,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int bx, con
     const float pxf = (float)g.px, pyf = (float)g.py;
     const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
     float4 *wA = sA[g.wid], *wB = sB[g.wid], *wAcc = sAcc[g.wid];
-    float *wC = sC[g.wid];
-    uint32_t *wId = sId[g.wid];
+    float *wC = sC[g.wid], *wAccF = reinterpret_cast<float *>(sAcc[g.wid]);
+    const int slot = acc_slot(lane);
 
     const float T_final = g.inside ? final_T[q] : 0.f;
     const uint32_t last = g.inside ? n_contrib[q] : 0u;
@@ -196,23 +218,27 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int bx, con
     // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
     float nC = 0.f;
-    uint32_t nId = 0;
-    if ((int64_t)lane <= max_last - 1) {
-        nId = point_list[g.r0 + (uint32_t)(max_last - 1 - lane)];
-        const float4 *s = reinterpret_cast<const float4 *>(splats + nId);
-        nA = s[0]; nB = s[1]; nC = s[2].x;
-    }
+    uint32_t nSlot = 0;  // where this lane's staged instance lives in its Gaussian's inst_pos slots
+    const int bin_x = g.bin % bx, bin_y = g.bin / bx;
+    auto stage = [&](uint32_t list_pos) {
+        const uint32_t id = point_list[list_pos];
+        const float4 *s = reinterpret_cast<const float4 *>(splats + id);
+        nA = s[0]; nB = s[1];
+        const float4 c = s[2];
+        nC = c.x;
+        const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
+        const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
+        nSlot = goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
+    };
+    if ((int64_t)lane <= max_last - 1) stage(g.r0 + (uint32_t)(max_last - 1 - lane));
     for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
         const int cnt = (int)min((int64_t)WAVE, top + 1);
         wave_sync_lds();
-        wA[lane] = nA; wB[lane] = nB; wC[lane] = nC; wId[lane] = nId;
+        wA[lane] = nA; wB[lane] = nB; wC[lane] = nC;
+        const uint32_t curSlot = nSlot;
         wave_sync_lds();
         const int64_t ntop = top - WAVE;
-        if (ntop - lane >= 0) {  // prefetch the next round
-            nId = point_list[g.r0 + (uint32_t)(ntop - lane)];
-            const float4 *s = reinterpret_cast<const float4 *>(splats + nId);
-            nA = s[0]; nB = s[1]; nC = s[2].x;
-        }
+        if (ntop - lane >= 0) stage(g.r0 + (uint32_t)(ntop - lane));  // prefetch the next round
         unsigned long long touched = 0ull;  // which staged splats received any gradient (wave-uniform)
         for (int j = 0; j < cnt; j++) {
             const uint32_t pos = (uint32_t)(top - j);
@@ -254,22 +280,19 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int W, int H, int bx, con
                 g_yy = -0.5f * gdy * dy * dL_dG;
                 g_op = G * dL_dalpha;
             }
-            float red[9] = {g_r, g_g, g_b, g_mx, g_my, g_xx, g_xy, g_yy, g_op};
-            wave_sum9_to_lane63(red);
-            if (lane == 63) {
-                wAcc[3 * j + 0] = make_float4(red[0], red[1], red[2], red[3]);
-                wAcc[3 * j + 1] = make_float4(red[4], red[5], red[6], red[7]);
-                wAcc[3 * j + 2] = make_float4(red[8], 0.f, 0.f, 0.f);
-            }
+            const float red[9] = {g_r, g_g, g_b, g_mx, g_my, g_xx, g_xy, g_yy, g_op};
+            const float out = wave_reduce_scatter9(red, (lane & 8) != 0);
+            if (slot >= 0) wAccF[12 * j + slot] = out;  // 12 lanes, 12 distinct words of this splat's record
         }
         wave_sync_lds();
-        if ((touched >> lane) & 1ull) {  // lane j flushes staged splat j: 9 atomics per (bin, splat)
-            const float4 v0 = wAcc[3 * lane], v1 = wAcc[3 * lane + 1];
-            const float v2 = wAcc[3 * lane + 2].x;
-            float *dst = reinterpret_cast<float *>(gacc + wId[lane]);
-            atomicAdd(dst + 0, v0.x); atomicAdd(dst + 1, v0.y); atomicAdd(dst + 2, v0.z); atomicAdd(dst + 3, v0.w);
-            atomicAdd(dst + 4, v1.x); atomicAdd(dst + 5, v1.y); atomicAdd(dst + 6, v1.z); atomicAdd(dst + 7, v1.w);
-            atomicAdd(dst + 8, v2);
+        if ((touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 48-byte instance record (no atomics)
+            const float4 v0 = wAcc[3 * lane], v1 = wAcc[3 * lane + 1], rs = wAcc[3 * lane + 2];
+            const uint32_t p = g.r0 + (uint32_t)(top - lane);  // consecutive lanes -> consecutive records: coalesced
+            float4 *dst = reinterpret_cast<float4 *>(inst_grad + p);
+            dst[0] = v0;
+            dst[1] = v1;
+            dst[2] = make_float4((rs.x + rs.y) + (rs.z + rs.w), 0.f, 0.f, 0.f);  // dL/dopacity arrives as 4 row sums
+            inst_pos[curSlot] = p;
         }
     }
 }
@@ -281,15 +304,16 @@ void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *spla
                               const GsrHeader *hdr, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_fwd, dim3(wgs), dim3(256), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
+    hipLaunchKernelGGL(k_composite_fwd, dim3(wgs), dim3(64 * WAVES), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
                        final_T, n_contrib, hdr);
 }
 
 void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
-                              const uint32_t *n_contrib, GsrGradAcc *gacc, const GsrHeader *hdr, hipStream_t s) {
+                              const uint32_t *n_contrib, const uint32_t *goff, uint32_t *inst_pos, GsrGradAcc *inst_grad,
+                              const GsrHeader *hdr, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(256), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
-                       final_T, n_contrib, gacc, hdr);
+    hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(64 * WAVES), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
+                       final_T, n_contrib, goff, inst_pos, inst_grad, hdr);
 }

@@ -159,8 +159,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             cap = _capacity_for(st, P)
+            # inference (no input needs a gradient): skip the backward tail of the workspace (52 B per instance slot)
+            ws_bytes = lib.gsr_workspace_bytes if any(ctx.needs_input_grad) else lib.gsr_workspace_bytes_forward_only
             while True:
-                nbytes = lib.gsr_workspace_bytes(P, W, H, cap)
+                nbytes = ws_bytes(P, W, H, cap)
                 ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
                 rc = lib.gsr_forward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),

@@ -71,7 +71,8 @@ typedef struct GsrHeader {      /* first bytes of the workspace, device memory *
     uint32_t reserved[11];
 } GsrHeader;
 
-size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity);
+size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity);              /* forward + backward */
+size_t gsr_workspace_bytes_forward_only(int P, int width, int height, int64_t instance_capacity); /* inference: no backward tail */
 
 /* Forward.  Inputs fp32, contiguous: means3D[P,3], colors[P,3], opacities[P], scales[P,3], rotations[P,4] (w,x,y,z;
  * NOT re-normalised), viewmatrix[16], projmatrix[16] (flat column-major = the transposed tensors the reference
