@@ -47,18 +47,15 @@ def main():
 
     import gps_gaussian_amd  # noqa: F401
     from gps_gaussian_amd import _capi, synthetic as S
+    from gps_gaussian_amd import dist as D
     from gps_gaussian_amd import rasterizer as RZ
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = D.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    D.init(backend="nccl", device=dev)  # "nccl" is RCCL on ROCm; no-op at world size 1
     _capi.lib()  # fail loudly if the HIP library is missing
 
     # ---- synthetic workload: one stereo pair per rank (different pose per rank), resident in HBM ------------------
@@ -93,8 +90,7 @@ def main():
                  scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
 
     def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
+        D.barrier(local_rank)
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -108,12 +104,7 @@ def main():
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        if world > 1:
-            x = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(x, op=dist.ReduceOp.MAX)
-            el = float(x.item())
-        return el
+        return D.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     # ---- the timed region: EXACTLY --steps fwd+bwd steps, hipEvents bracketing every kernel on the launch stream ----
     RZ.set_stage_timing(True)
@@ -137,16 +128,18 @@ def main():
     torch.cuda.synchronize(dev)
 
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------------
-    T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    NB = (((W + 7) // 8 + 3) // 4 * 4) * ((H + 7) // 8)  # 8x8-pixel bins (one wave64 each), DESIGN.md section 2
     npix = W * H
-    alg_bytes = {  # ALGORITHMIC bytes per launch: each input read once, each output written once
-        "preprocess": 44 * P + 48 * P + 4 * P,
-        "scan": 8 * T_tiles,
+    # ALGORITHMIC bytes per launch (SURVEY.md section 8d convention: each input read once, each output
+    # written once; R = measured (Gaussian, bin) instances, NB = bins)
+    alg_bytes = {
+        "preprocess": 96 * P,
+        "scan": 8 * NB,
         "scatter": 16 * P + 8 * R,
-        "sort": 8 * R + 4 * R + 8 * T_tiles,
-        "composite_fwd": 40 * R + 8 * T_tiles + 12 * npix + 8 * npix,
-        "composite_bwd": 40 * R + 8 * T_tiles + 20 * npix + 44 * P,
-        "preprocess_bwd": 48 * P + 44 * P + 68 * P,
+        "sort": 12 * R + 8 * NB,
+        "composite_fwd": 40 * R + 8 * NB + 20 * npix,
+        "composite_bwd": 40 * R + 8 * NB + 20 * npix + 44 * P,
+        "preprocess_bwd": 212 * P,
     }
     per_stage = {}
     for name, (ms, n) in stages.items():
@@ -169,8 +162,9 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": per_stage[dom]["avg_us"],
                     # compositing is FP32-VALU/LDS bound, not HBM bound: lane-op roofline of the same kernel
-                    "valu_lane_ops_per_launch": 256 * R * (60 if dom == "composite_bwd" else 30),
-                    "valu_frac": round(256 * R * (60 if dom == "composite_bwd" else 30) / (per_stage[dom]["avg_us"] * 1e-6)
+                    # 64 pixels per (Gaussian, bin) instance; ~30 lane-ops per pair forward, ~60 backward
+                    "valu_lane_ops_per_launch": 64 * R * (60 if dom == "composite_bwd" else 30),
+                    "valu_frac": round(64 * R * (60 if dom == "composite_bwd" else 30) / (per_stage[dom]["avg_us"] * 1e-6)
                                        / (VALU_PEAK_TLANEOPS * 1e12), 4)}
 
     # ---- CPU baseline: the fp32 oracle on the host cores (rank 0, N=1 only), bounded sample ------------------------------
@@ -194,7 +188,7 @@ def main():
             "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward", "value": round(value, 2),
             "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d instances, "
+            "config": {"workload": "BASELINE config 2: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d (Gaussian, 8x8-bin) instances, "
                                    "HIP rasteriser forward+backward, one view per step per GPU" % (W, H, P, R),
                        "check_mode": "sync (exact; 64-byte header read back at the end of every forward)"},
             "roofline": roofline, "cpu_baseline": cpu,
@@ -203,8 +197,7 @@ def main():
             "stages": per_stage,
         }
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,71 @@
+"""CPU, world_size 2, gloo: the multi-process protocol of the render path (view sharding, barrier + MAX timing as
+bench.py does it, rank-0 JSON line) and the stage-2 gradient all-reduce helper."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch
+    import gps_gaussian_amd
+    from gps_gaussian_amd import dist as D
+
+    rank, local_rank, world = D.init(backend="gloo")
+    assert world == 2 and rank in (0, 1)
+    # --- view sharding: disjoint, complete, balanced
+    mine = D.shard_views(7, rank, world)
+    import torch.distributed as dist
+    gathered = [None, None]
+    dist.all_gather_object(gathered, mine)
+    allv = sorted(sum(gathered, []))
+    assert allv == list(range(7)) and abs(len(gathered[0]) - len(gathered[1])) <= 1
+    # --- timing protocol of bench.py: barrier, K steps, barrier, MAX over ranks
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))          # rank 1 is the slow one
+    D.barrier()
+    el = D.max_over_ranks(time.perf_counter() - t0)
+    assert el >= 0.1 - 1e-3
+    # --- stage-2 exchange step: bucketed mean all-reduce, including a parameter that never gets a gradient
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+    unused = torch.nn.Linear(4, 4)         # like gru16/gru32 in the reference: constructed, never used
+    params = list(net.parameters()) + list(unused.parameters())
+    x = torch.full((3, 8), float(rank + 1))
+    net(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    red = D.GradAllReducer(params, bucket_bytes=300)   # tiny buckets -> several collectives
+    assert len(red.buckets) > 1
+    red()
+    both = [None, None]
+    dist.all_gather_object(both, [g.tolist() for g in local])
+    for p, g0, g1 in zip(net.parameters(), both[0], both[1]):
+        want = (torch.tensor(g0) + torch.tensor(g1)) / 2
+        assert torch.allclose(p.grad, want, atol=1e-6)
+    for p in unused.parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) == 0.0
+    if rank == 0:
+        print(json.dumps({"metric": "protocol", "n_gpus": world, "value": 2 / el, "views": allv}))
+    D.shutdown()
+""")
+
+
+def test_two_rank_protocol_and_grad_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["views"] == list(range(7))
