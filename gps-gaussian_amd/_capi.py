@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
-    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_backward", "gsr_read_header",
+    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_timing_read", "cs_forward", "cs_backward",
 )
 
@@ -50,6 +50,8 @@ def lib():
     l.gsr_backward.restype = i32
     l.gsr_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                vp, vp, sz, i64, u32, vp]
+    l.gsr_copy_header_async.restype = i32
+    l.gsr_copy_header_async.argtypes = [vp, vp, vp]
     l.gsr_read_header.restype = i32
     l.gsr_read_header.argtypes = [vp, C.POINTER(GsrHeader), vp]
     l.gsr_export_state.restype = i32

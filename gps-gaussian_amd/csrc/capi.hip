@@ -30,6 +30,8 @@ struct StageTimer {  // RAII: records an event pair around one stage when timing
     int slot;
     hipStream_t s;
     StageTimer(unsigned flags, int stage, hipStream_t s_) : on((flags & GSR_FLAG_TIMING) != 0), slot(-1), s(s_) {
+        const unsigned only = (flags >> 4) & 0xFu;  // GSR_FLAG_TIMING_STAGE(k): bracket stage k only (less perturbation)
+        if (only && (int)only - 1 != stage) on = false;
         if (!on || g_rec.n >= TIMING_MAX) { on = false; return; }
         slot = g_rec.n++;
         if (slot >= g_rec.created) {
@@ -206,6 +208,11 @@ extern "C" int gsr_timing_read(float *ms_sum_host, int *launches_host) {
     }
     g_rec.n = 0;
     return GPSGS_OK;
+}
+
+extern "C" int gsr_copy_header_async(const void *workspace, void *host_pinned_out, void *stream) {
+    if (!workspace || !host_pinned_out) return GPSGS_E_INVALID;
+    return hipMemcpyAsync(host_pinned_out, workspace, 16, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
 }
 
 extern "C" int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream) {

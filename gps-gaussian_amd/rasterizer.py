@@ -45,10 +45,16 @@ class GaussianRasterizationSettings(NamedTuple):
 _extra_flags = 0  # bench.py sets GSR_FLAG_TIMING here to bracket every kernel with hipEvents
 
 
-def set_stage_timing(on):
-    """Turn per-stage hipEvent recording on/off for subsequent calls (read with _capi.timing_read())."""
+def set_stage_timing(on, stage=None):
+    """Turn hipEvent bracketing of the kernels on/off for subsequent calls (read with _capi.timing_read()).
+    stage: name from _capi.STAGES to bracket only that kernel (2 events per call instead of ~20)."""
     global _extra_flags
-    _extra_flags = _capi.GSR_FLAG_TIMING if on else 0
+    if not on:
+        _extra_flags = 0
+    elif stage is None:
+        _extra_flags = _capi.GSR_FLAG_TIMING
+    else:
+        _extra_flags = _capi.GSR_FLAG_TIMING | ((_capi.STAGES.index(stage) + 1) << 4)
 
 
 # ---- capacity policy --------------------------------------------------------------------------------------------
@@ -104,15 +110,43 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _HeaderRing:
+    """Pinned 16-byte header slots + reusable events (allocating pinned memory / events per call costs tens of us)."""
+
+    def __init__(self, n=64):
+        self.buf = torch.zeros((n, 2), dtype=torch.int64).pin_memory()
+        self.np = self.buf.numpy()  # same memory; plain numpy scalars are much cheaper to read than 0-d tensors
+        self.base = self.buf.data_ptr()
+        self.events = [torch.cuda.Event() for _ in range(n)]
+        self.n, self.i = n, 0
+
+    def next(self):
+        i = self.i
+        self.i = (i + 1) % self.n
+        return self.np[i], C.c_void_p(self.base + 16 * i), self.events[i]
+
+
+_rings = {}
+
+
+def _ring(dev):
+    r = _rings.get(dev.index)
+    if r is None:
+        r = _rings[dev.index] = _HeaderRing()
+    return r
+
+
 def _prep(t, name, shape_tail, device):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a tensor" % name)
     if t.device != device:
         raise RuntimeError("gps_gaussian_amd: %s is on %s but means3D is on %s (no CPU path exists)" % (name, t.device, device))
-    t = t.detach()
+    if t.requires_grad:
+        t = t.detach()
     if t.dtype != torch.float32:
         t = t.float()
-    t = t.contiguous()
+    if not t.is_contiguous():
+        t = t.contiguous()
     if t.data_ptr() % 16:
         t = t.clone()
     if shape_tail is not None and (t.dim() < 1 or tuple(t.shape[1:]) != shape_tail):
@@ -122,10 +156,27 @@ def _prep(t, name, shape_tail, device):
 
 def _cam(t, n, device):
     # H1: in training the camera tensors arrive as pinned CPU tensors, in the test scripts as GPU tensors
-    t = t.detach().to(device=device, dtype=torch.float32, non_blocking=True).contiguous().reshape(-1)
+    if t.device != device or t.dtype != torch.float32 or t.requires_grad or not t.is_contiguous():
+        t = t.detach().to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
     if t.numel() != n:
         raise RuntimeError("camera tensor must have %d elements" % n)
     return t
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def _device_guard(dev):
+    # switching the current device costs ~10 us; skip it when the tensors already live on the current device
+    return _NOGUARD if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -153,9 +204,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags
         mode = _check_mode()
         st = _dev_state(dev)
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             _drain_pending(st)
-            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            cur_stream = torch.cuda.current_stream(dev)
+            stream = C.c_void_p(cur_stream.cuda_stream)
+            ring = _ring(dev)
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             cap = _capacity_for(st, P)
@@ -170,10 +223,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _capi.check(rc, "gsr_forward")
                 if P == 0:
                     break
-                hdr = torch.empty((2,), dtype=torch.int64).pin_memory()
-                hdr.copy_(ws[:16].view(torch.int64), non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
+                if mode == "deferred" and len(st["pending"]) >= ring.n - 1:
+                    _drain_pending(st, block=True)  # never reuse a pinned slot that is still in flight
+                hdr, hdr_ptr, ev = ring.next()
+                _capi.check(lib.gsr_copy_header_async(_ptr(ws), hdr_ptr, stream), "gsr_copy_header_async")
+                ev.record(cur_stream)
                 if mode == "deferred":
                     st["pending"].append((ev, hdr, P))
                     break
@@ -198,7 +252,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = m3.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         g = grad_out_color.detach().to(dtype=torch.float32).contiguous()  # H3: may arrive non-contiguous
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             st = _dev_state(dev)
             _drain_pending(st, block=(_check_mode() == "deferred"))
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -44,6 +44,7 @@ enum {
 /* flags for gsr_forward / gsr_backward */
 #define GSR_FLAG_DEBUG 1u  /* synchronise and check after every kernel (the reference hard-codes debug=False) */
 #define GSR_FLAG_TIMING 2u /* bracket every stage with hipEvents on `stream`; read them with gsr_timing_read() */
+#define GSR_FLAG_TIMING_STAGE(k) (GSR_FLAG_TIMING | (((unsigned)(k) + 1u) << 4)) /* ... or only stage k (GSR_STAGE_*) */
 
 /* stage ids reported by gsr_timing_read() */
 enum {
@@ -91,6 +92,10 @@ int gsr_backward(int P, int width, int height, const float *means3D, const float
                  const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors,
                  float *dL_dopacity, float *dL_dscales, float *dL_drotations, void *workspace,
                  size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream);
+
+/* Enqueues a copy of the first 16 header bytes {u64 num_rendered, u32 overflow, u32 max_bin_count} to PINNED host memory on
+ * `stream`; does not synchronise (the host reads it after an event / stream sync of its own). */
+int gsr_copy_header_async(const void *workspace, void *host_pinned_out, void *stream);
 
 /* Blocking helper for non-torch hosts: copies the header to host memory and synchronises `stream`. */
 int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream);
