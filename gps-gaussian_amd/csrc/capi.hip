@@ -135,7 +135,7 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SORT, s);
-        gsr_launch_sort(L.NB, bin_offset, keys, point_list, hdr, s);
+        gsr_launch_sort(L.NB, bin_offset, wg_order, keys, point_list, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {

@@ -9,8 +9,8 @@
 //              ones drain in the gaps), in image order within each class (keeps neighbouring bins on neighbouring CUs).
 //   k_scatter  each Gaussian drops (depth_bits<<32 | id) into its bins' segments; slots are reserved with ONE returning
 //              global atomic per (workgroup, bin) after an LDS histogram (gsr_block_bin), not one per instance.
-//   k_sort_*   one workgroup per bin sorts its segment in LDS with an ascending-only bitonic network on the
-//              64-bit key.  Keys are unique (id in the low word) so the result is deterministic and equals
+//   k_sort_*   one WAVE per bin (lists <= 1024; larger ones get a 256- or 1024-thread workgroup) sorts its segment in LDS
+//              with an ascending-only bitonic network on the 64-bit key.  Keys are unique (id in the low word) so the result is deterministic and equals
 //              upstream's stable radix order: depth ascending, ties by Gaussian index.
 //              Segments longer than the LDS capacity fall back to the same network run in global memory.
 // HBM traffic: 8 B written + 8 B read + 4 B written per instance, versus >= 144 B for the global radix sort.
@@ -137,9 +137,20 @@ __device__ __forceinline__ void cmpx(PtrT a, uint32_t i, uint32_t j, uint32_t n)
     }
 }
 
+__device__ __forceinline__ void sort_sync(bool wave_only) {
+    if (wave_only) {  // a single wave owns the segment: the DS queue is in order, only the compiler needs pinning
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // Bitonic network with ascending-only comparators ("flip" first step, then half-cleaners).
 template <int THREADS, typename PtrT>
 __device__ __forceinline__ void bitonic_sort(PtrT a, uint32_t n, uint32_t n2, int tid) {
+    constexpr bool WV = THREADS == 64;
     const uint32_t half = n2 >> 1;
     for (uint32_t kb = 1; (1u << kb) <= n2; kb++) {  // k = 2^kb: merge sorted runs of k/2 into runs of k
         const uint32_t hk = 1u << (kb - 1);
@@ -147,14 +158,14 @@ __device__ __forceinline__ void bitonic_sort(PtrT a, uint32_t n, uint32_t n2, in
             const uint32_t blk = idx >> (kb - 1), off = idx & (hk - 1);
             cmpx(a, (blk << kb) + off, (blk << kb) + (2 * hk - 1) - off, n);
         }
-        __syncthreads();
+        sort_sync(WV);
         for (int jb = (int)kb - 2; jb >= 0; jb--) {  // half-cleaners, stride j = 2^jb
             const uint32_t j = 1u << jb;
             for (uint32_t idx = tid; idx < half; idx += THREADS) {
                 const uint32_t i = ((idx >> jb) << (jb + 1)) | (idx & (j - 1));
                 cmpx(a, i, i + j, n);
             }
-            __syncthreads();
+            sort_sync(WV);
         }
     }
 }
@@ -176,7 +187,7 @@ __device__ __forceinline__ void sort_one_bin(uint64_t *sk, uint32_t off, uint32_
     const uint32_t n2 = next_pow2(n);
     if (n <= (uint32_t)CAP) {
         for (uint32_t i = tid; i < n; i += THREADS) sk[i] = seg[i];
-        __syncthreads();
+        sort_sync(THREADS == 64);
         bitonic_sort<THREADS>(sk, n, n2, tid);
         for (uint32_t i = tid; i < n; i += THREADS) point_list[off + i] = (uint32_t)sk[i];
     } else if (GLOBAL_FALLBACK) {
@@ -187,14 +198,95 @@ __device__ __forceinline__ void sort_one_bin(uint64_t *sk, uint32_t off, uint32_
     }
 }
 
-// lists of 1..2048 keys: one 256-thread workgroup per bin, 16 KiB LDS
-__global__ __launch_bounds__(256) void k_sort_small(const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
+// ---- register-resident bitonic sort: one wave, KPL keys per lane (element e = lane*KPL + r), no LDS memory traffic ------
+// The LDS network above moves 4 x 64-bit LDS accesses per compare-exchange and was LDS-throughput bound (45 steps x 4 CEs
+// per lane x ~16 LDS cycles for 512 keys).  Here every partner is `e ^ mask`, so strides below KPL are register-to-
+// register and the rest are lane-xor exchanges (ds_bpermute through the LDS crossbar, no bank access): ~4x less LDS
+// pressure and no barrier of any kind.  Lists are padded to 64*KPL with +inf keys, so every comparator is unconditional.
+template <int KPL>
+__device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, int lane) {
+    constexpr int LOGK = KPL == 1 ? 0 : KPL == 2 ? 1 : KPL == 4 ? 2 : KPL == 8 ? 3 : 4;
+    constexpr int LOGN = LOGK + 6;
+    uint64_t key[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t e = (uint32_t)lane * KPL + r;
+        key[r] = e < n ? seg[e] : ~0ull;
+    }
+#pragma unroll
+    for (int kb = 1; kb <= LOGN; kb++) {
+#pragma unroll
+        for (int st = 0; st < kb; st++) {  // st = 0: flip (mask = 2^kb - 1); st > 0: half-cleaner of stride 2^(kb-1-st)
+            const uint32_t mask = st == 0 ? ((1u << kb) - 1u) : (1u << (kb - 1 - st));
+            const uint32_t top = st == 0 ? (1u << (kb - 1)) : mask;  // the element without this bit is the lower of its pair
+            const uint32_t rmask = mask & (KPL - 1), lmask = mask >> LOGK;
+            if (lmask == 0) {  // both elements live in this lane's registers
+#pragma unroll
+                for (int r = 0; r < KPL; r++) {
+                    const int r2 = r ^ (int)rmask;
+                    if (r2 > r) {
+                        const uint64_t a = key[r], b = key[r2];
+                        const bool sw = a > b;
+                        key[r] = sw ? b : a;
+                        key[r2] = sw ? a : b;
+                    }
+                }
+            } else {  // partner element lives in lane ^ lmask, register r ^ rmask
+                const bool lower = ((uint32_t)lane & (top >> LOGK)) == 0;
+                uint64_t other[KPL];
+#pragma unroll
+                for (int r = 0; r < KPL; r++) {
+                    const uint64_t mine = key[r ^ (int)rmask];
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine, (int)lmask, 64);
+                    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), (int)lmask, 64);
+                    other[r] = ((uint64_t)hi << 32) | lo;
+                }
+#pragma unroll
+                for (int r = 0; r < KPL; r++) {
+                    const uint64_t a = key[r], b = other[r];
+                    const bool take = lower ? (b < a) : (b > a);
+                    key[r] = take ? b : a;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t e = (uint32_t)lane * KPL + r;
+        if (e < n) out[e] = (uint32_t)key[r];
+    }
+}
+
+// lists of 1..1024 keys (the common case: a body bin holds ~450): ONE WAVE per bin, keys in registers.
+__global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                                                  const GsrHeader *__restrict__ hdr) {
+    if (hdr->overflow || blockIdx.x >= hdr->num_busy_wgs) return;
+    const uint32_t bin = wg_order[blockIdx.x];  // busy bins first
+    const uint32_t off = bin_offset[bin], n = bin_offset[bin + 1] - off;
+    if (n == 0 || n > 1024u) return;
+    const uint64_t *seg = keys + off;
+    uint32_t *out = point_list + off;
+    const int lane = threadIdx.x;
+    if (n <= 64u) sort_wave_regs<1>(seg, n, out, lane);
+    else if (n <= 128u) sort_wave_regs<2>(seg, n, out, lane);
+    else if (n <= 256u) sort_wave_regs<4>(seg, n, out, lane);
+    else if (n <= 512u) sort_wave_regs<8>(seg, n, out, lane);
+    else sort_wave_regs<16>(seg, n, out, lane);
+}
+
+// lists of 1025..2048 keys: one 256-thread workgroup per bin, 16 KiB LDS (persistent small grid, rarely any work)
+__global__ __launch_bounds__(256) void k_sort_small(int NB, const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
                                                     uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
     __shared__ uint64_t sk[2048];
-    if (hdr->overflow) return;
-    const uint32_t off = bin_offset[blockIdx.x], n = bin_offset[blockIdx.x + 1] - off;
-    if (n == 0 || n > 2048u) return;
-    sort_one_bin<256, 2048, false>(sk, off, n, keys, point_list, threadIdx.x);
+    if (hdr->overflow || hdr->max_tile_count <= 1024u) return;
+    for (int b = blockIdx.x; b < NB; b += gridDim.x) {
+        const uint32_t off = bin_offset[b], n = bin_offset[b + 1] - off;  // wave-uniform
+        if (n > 1024u && n <= 2048u) {
+            sort_one_bin<256, 2048, false>(sk, off, n, keys, point_list, threadIdx.x);
+            __syncthreads();
+        }
+    }
 }
 
 // lists longer than 2048 keys are rare: a small persistent grid of 1024-thread workgroups (128 KiB LDS each) strides
@@ -226,8 +318,10 @@ void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cur
     hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, bin_cursor, keys, hdr);
 }
 
-void gsr_launch_sort(int NB, const uint32_t *bin_offset, uint64_t *keys, uint32_t *point_list, const GsrHeader *hdr, hipStream_t s) {
+void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
+                     const GsrHeader *hdr, hipStream_t s) {
     if (NB <= 0) return;
-    hipLaunchKernelGGL(k_sort_small, dim3(NB), dim3(256), 0, s, bin_offset, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_small, dim3(NB < 1024 ? NB : 1024), dim3(256), 0, s, NB, bin_offset, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 256 ? NB : 256), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

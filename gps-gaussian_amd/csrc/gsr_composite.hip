@@ -254,7 +254,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
             if (!__any(valid)) continue;  // wave-uniform
             touched |= 1ull << j;
 
-            float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_mx = 0.f, g_my = 0.f, g_xx = 0.f, g_xy = 0.f, g_yy = 0.f, g_op = 0.f;
+            // Per pair only the colour terms and six MOMENTS of s = dL/dG * G are formed: S0 = sum s, Sx = sum s dx, Sy, Sxx,
+            // Sxy, Syy.  dL/dmean2D, dL/dconic and dL/dopacity are linear in them and are finished once per (bin, splat)
+            // at flush time (11 fewer instructions per pair than forming the nine upstream terms here).
+            float g_r = 0.f, g_g = 0.f, g_b = 0.f, m_x = 0.f, m_y = 0.f, m_xx = 0.f, m_xy = 0.f, m_yy = 0.f, m_0 = 0.f;
             if (valid) {
                 const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = T * rcp;
@@ -271,29 +274,31 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
                 dL_dalpha *= T;
                 last_alpha = alpha;
                 dL_dalpha += (-T_final * rcp) * bg_dot;
-                const float dL_dG = b.y * dL_dalpha;  // straight through the 0.99 clamp, like upstream
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                g_my = dL_dG * dG_ddely * ddely_dy;
-                g_xx = -0.5f * gdx * dx * dL_dG;
-                g_xy = -0.5f * gdx * dy * dL_dG;
-                g_yy = -0.5f * gdy * dy * dL_dG;
-                g_op = G * dL_dalpha;
+                m_0 = (b.y * dL_dalpha) * G;  // s = dL/dG * G, with dL/dG = opacity * dL/dalpha straight through the 0.99 clamp
+                m_x = m_0 * dx;
+                m_y = m_0 * dy;
+                m_xx = m_x * dx;
+                m_xy = m_x * dy;
+                m_yy = m_y * dy;
             }
-            const float red[9] = {g_r, g_g, g_b, g_mx, g_my, g_xx, g_xy, g_yy, g_op};
+            const float red[9] = {g_r, g_g, g_b, m_x, m_y, m_xx, m_xy, m_yy, m_0};
             const float out = wave_reduce_scatter9(red, (lane & 8) != 0);
             if (slot >= 0) wAccF[12 * j + slot] = out;  // 12 lanes, 12 distinct words of this splat's record
         }
         wave_sync_lds();
         if ((touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 48-byte instance record (no atomics)
             const float4 v0 = wAcc[3 * lane], v1 = wAcc[3 * lane + 1], rs = wAcc[3 * lane + 2];
+            const float4 sa = wA[lane], sb = wB[lane];  // this lane staged splat `lane` itself: conic (sa.z, sa.w, sb.x), opacity sb.y
+            const float Sx = v0.w, Sy = v1.x, Sxx = v1.y, Sxy = v1.z, Syy = v1.w;
+            const float S0 = (rs.x + rs.y) + (rs.z + rs.w);  // arrives as 4 row sums
+            // dG/d(delta) = -G (A dx + B dy), -G (C dy + B dx);  dL/dconic = -0.5 s {dx^2, dx dy, dy^2};  dL/dop = G dL/dalpha = s / op
+            const float g_mx = ddelx_dx * (-sa.z * Sx - sa.w * Sy);
+            const float g_my = ddely_dy * (-sb.x * Sy - sa.w * Sx);
             const uint32_t p = g.r0 + (uint32_t)(top - lane);  // consecutive lanes -> consecutive records: coalesced
             float4 *dst = reinterpret_cast<float4 *>(inst_grad + p);
-            dst[0] = v0;
-            dst[1] = v1;
-            dst[2] = make_float4((rs.x + rs.y) + (rs.z + rs.w), 0.f, 0.f, 0.f);  // dL/dopacity arrives as 4 row sums
+            dst[0] = make_float4(v0.x, v0.y, v0.z, g_mx);
+            dst[1] = make_float4(g_my, -0.5f * Sxx, -0.5f * Sxy, -0.5f * Syy);
+            dst[2] = make_float4(S0 * __builtin_amdgcn_rcpf(sb.y), 0.f, 0.f, 0.f);
             inst_pos[curSlot] = p;
         }
     }

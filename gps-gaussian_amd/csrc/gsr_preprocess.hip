@@ -242,15 +242,25 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         float g2x = 0.f;
         const uint32_t s0 = goff[i], s1 = goff[i + 1];
-        for (uint32_t sl = s0; sl < s1; sl++) {
-            const uint32_t pi = inst_pos[sl];
-            if (pi != 0xffffffffu) {
-                const float4 *r4 = reinterpret_cast<const float4 *>(inst_grad + pi);
-                const float4 a0 = r4[0], a1 = r4[1];
-                const float a2 = r4[2].x;
-                g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
-                g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
-                g2x += a2;
+        for (uint32_t sl = s0; sl < s1; sl += 4) {  // 4 slots per step: all position loads, then all record loads, then sum in order
+            uint32_t pi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pi[u] = (sl + u < s1) ? inst_pos[sl + u] : 0xffffffffu;
+            float4 a0[4], a1[4];
+            float a2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool ok = pi[u] != 0xffffffffu;
+                const float4 *r4 = reinterpret_cast<const float4 *>(inst_grad + (ok ? pi[u] : 0u));
+                a0[u] = ok ? r4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                a1[u] = ok ? r4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                a2[u] = ok ? r4[2].x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                g0.x += a0[u].x; g0.y += a0[u].y; g0.z += a0[u].z; g0.w += a0[u].w;
+                g1.x += a1[u].x; g1.y += a1[u].y; g1.z += a1[u].z; g1.w += a1[u].w;
+                g2x += a2[u];
             }
         }
         const float4 g2 = make_float4(g2x, 0.f, 0.f, 0.f);
