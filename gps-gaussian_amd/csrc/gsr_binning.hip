@@ -114,14 +114,20 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, cons
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t lo = 0, hi = 0;
     uint64_t key = 0;
+    GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
     if (i < P) {
-        const float4 c = reinterpret_cast<const float4 *>(splats + i)[2];
+        const float4 *rec = reinterpret_cast<const float4 *>(splats + i);
+        const float4 c = rec[2];
         lo = __float_as_uint(c.z);
         hi = __float_as_uint(c.w);
         key = ((uint64_t)__float_as_uint(c.y) << 32) | (uint32_t)i;
+        if ((hi & 0xffff) > (lo & 0xffff)) {  // listed somewhere: the same predicate k_preprocess counted with
+            const float4 a = rec[0], b = rec[1];
+            hit = gsr_hit_setup(a.x, a.y, a.z, a.w, b.x, b.y);
+        }
     }
     gsr_block_bin<true>(
-        lo, hi, bx, [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
+        lo, hi, bx, [&](int x, int y) { return gsr_bin_hit(hit, x, y); }, [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
         [&](uint32_t pos) { keys[pos] = key; });
 }
 

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
                                                                uint32_t *__restrict__ bin_count, GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t rlo = 0, rhi = 0;
+    GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
     if (i < q.P) {
     const Cam cam = load_cam(q.view, q.proj);
     const float p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
                     if (b1x > b0x && b1y > b0y) {
                         rlo = (uint32_t)b0x | ((uint32_t)b0y << 16);
                         rhi = (uint32_t)b1x | ((uint32_t)b1y << 16);
+                        hit = gsr_hit_setup(px, py, c * det_inv, -b * det_inv, a * det_inv, op);  // from the STORED record values
                     }
                 }
             }
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     q.radii[i] = radius;
     }
     gsr_block_bin<false>(
-        rlo, rhi, q.bx, [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {});
+        rlo, rhi, q.bx, [&](int x, int y) { return gsr_bin_hit(hit, x, y); }, [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {});
 }
 
 // exclusive prefix over Gaussians of their bin-rect area (= number of inst_pos slots); two-phase, 1024 per block
