@@ -115,7 +115,13 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     q.P = P; q.W = width; q.H = height; q.gx = L.gx; q.gy = L.gy; q.bx = L.bx; q.by = L.by; q.bx_real = L.bx_real;
     q.means3D = means3D; q.colors = colors; q.opacities = opacities; q.scales = scales; q.rotations = rotations;
     q.scale_modifier = scale_modifier; q.tanfovx = tanfovx; q.tanfovy = tanfovy;
-    q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity; q.dbg = flags >> 8;
+    q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity;
+    // a workspace that includes the backward tail gets the per-Gaussian slot prefix and cleared inst_pos slots from the forward
+    const bool training = workspace_bytes >= L.total;
+    q.goff = training ? reinterpret_cast<uint32_t *>(at(workspace, L.goff)) : nullptr;
+    q.gpart = training ? reinterpret_cast<uint32_t *>(at(workspace, L.gscan_part)) : nullptr;
+    uint32_t *inst_pos_fwd = training ? reinterpret_cast<uint32_t *>(at(workspace, L.inst_pos)) : nullptr;
+    const int n_gblocks = (P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS;
 
     int rc;
     {
@@ -125,12 +131,12 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCAN, s);
-        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, s);
+        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, q.gpart, n_gblocks, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, L.bx, splats, bin_cursor, keys, hdr, s);
+        gsr_launch_scatter(P, L.bx, splats, bin_cursor, keys, hdr, q.goff, q.gpart, inst_pos_fwd, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
@@ -172,14 +178,11 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     uint32_t *inst_pos = reinterpret_cast<uint32_t *>(at(workspace, L.inst_pos));
     GsrGradAcc *inst_grad = reinterpret_cast<GsrGradAcc *>(at(workspace, L.inst_grad));
 
-    // inst_pos = ~0 ("no record"): only instances the compositing backward actually reaches get a record
-    if (hipMemsetAsync(inst_pos, 0xff, (size_t)(instance_capacity > 0 ? instance_capacity : 1) * 4, s) != hipSuccess) return GPSGS_E_LAUNCH;
-    gsr_launch_gauss_scan(P, splats, goff, gscan_part, s);
+    // goff / gscan_part / cleared inst_pos slots were produced by the matching gsr_forward (training workspace)
     int rc;
-    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_COMPOSITE_BWD, s);
-        gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, inst_pos, inst_grad, hdr, s);
+        gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_pos, inst_grad, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     GsrBwdParams b;
@@ -191,7 +194,7 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
     {
         StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);
-        gsr_launch_preprocess_bwd(b, splats, goff, inst_pos, inst_grad, s);
+        gsr_launch_preprocess_bwd(b, splats, goff, gscan_part, inst_pos, inst_grad, s);
     }
     return check(s, flags);
 }

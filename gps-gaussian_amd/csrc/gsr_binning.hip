@@ -71,7 +71,7 @@ __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_
 __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, const uint4 *__restrict__ part,
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
                                                uint32_t *__restrict__ wg_order, int NB, int nblocks, int64_t cap,
-                                               GsrHeader *__restrict__ hdr) {
+                                               GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks) {
     __shared__ uint32_t wsum[SB / 64];
     const int tid = threadIdx.x;
     uint32_t pre_sum = 0, pre_busy = 0, tot_sum = 0, tot_busy = 0, tot_max = 0;
@@ -98,6 +98,17 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         const uint32_t nbusy_before = pre_busy + bpos;
         wg_order[busy ? nbusy_before : tot_busy + (w - nbusy_before)] = w;
     }
+    if (blockIdx.x == 0 && gpart) {  // training: block sums of the per-Gaussian slot counts -> exclusive prefix, in place
+        uint32_t carry = 0;
+        for (int base = 0; base < n_gblocks; base += SB) {
+            const int k = base + tid;
+            const uint32_t v = k < n_gblocks ? gpart[k] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_exscan(v, wsum, &tot);
+            if (k < n_gblocks) gpart[k] = carry + ex;
+            carry += tot;
+        }
+    }
     if (blockIdx.x == 0 && tid == 0) {
         bin_offset[NB] = tot_sum;
         hdr->num_rendered = tot_sum;
@@ -109,7 +120,8 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
 
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats,
                                                             uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
-                                                            const GsrHeader *__restrict__ hdr) {
+                                                            const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
+                                                            const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos) {
     if (hdr->overflow) return;
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t lo = 0, hi = 0;
@@ -124,6 +136,11 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, cons
         if ((hi & 0xffff) > (lo & 0xffff)) {  // listed somewhere: the same predicate k_preprocess counted with
             const float4 a = rec[0], b = rec[1];
             hit = gsr_hit_setup(a.x, a.y, a.z, a.w, b.x, b.y);
+            if (inst_pos) {  // training: mark this Gaussian's instance slots "no record yet" (replaces a 4*cap-byte memset)
+                const uint32_t s0 = gpart[i >> 10] + goff[i];
+                const uint32_t area = ((hi & 0xffff) - (lo & 0xffff)) * ((hi >> 16) - (lo >> 16));
+                for (uint32_t k = 0; k < area; k++) inst_pos[s0 + k] = 0xffffffffu;
+            }
         }
     }
     gsr_block_bin<true>(
@@ -281,29 +298,15 @@ __global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ b
     else sort_wave_regs<16>(seg, n, out, lane);
 }
 
-// lists of 1025..2048 keys: one 256-thread workgroup per bin, 16 KiB LDS (persistent small grid, rarely any work)
-__global__ __launch_bounds__(256) void k_sort_small(int NB, const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
-                                                    uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
-    __shared__ uint64_t sk[2048];
-    if (hdr->overflow || hdr->max_tile_count <= 1024u) return;
-    for (int b = blockIdx.x; b < NB; b += gridDim.x) {
-        const uint32_t off = bin_offset[b], n = bin_offset[b + 1] - off;  // wave-uniform
-        if (n > 1024u && n <= 2048u) {
-            sort_one_bin<256, 2048, false>(sk, off, n, keys, point_list, threadIdx.x);
-            __syncthreads();
-        }
-    }
-}
-
-// lists longer than 2048 keys are rare: a small persistent grid of 1024-thread workgroups (128 KiB LDS each) strides
+// lists longer than 1024 keys are rare: a small persistent grid of 1024-thread workgroups (128 KiB LDS each) strides
 // over the bins and picks them up (launching one big workgroup per bin just to exit cost ~18 us at 16,384 bins)
 __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
                                                      uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
     __shared__ uint64_t sk[16384];
-    if (hdr->overflow || hdr->max_tile_count <= 2048u) return;
+    if (hdr->overflow || hdr->max_tile_count <= 1024u) return;
     for (int b = blockIdx.x; b < NB; b += gridDim.x) {
         const uint32_t off = bin_offset[b], n = bin_offset[b + 1] - off;  // wave-uniform
-        if (n > 2048u) {
+        if (n > 1024u) {
             sort_one_bin<1024, 16384, true>(sk, off, n, keys, point_list, threadIdx.x);
             __syncthreads();
         }
@@ -313,21 +316,23 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 }  // namespace
 
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
-                     int64_t cap, GsrHeader *hdr, hipStream_t s) {
+                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, hipStream_t s) {
     const int nblocks = (NB + SB - 1) / SB;
     hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB);
-    hipLaunchKernelGGL(k_scan_b, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr);
+    hipLaunchKernelGGL(k_scan_b, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr,
+                       gpart, n_gblocks);
 }
 
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s) {
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+                        const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, bin_cursor, keys, hdr);
+    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, bin_cursor, keys, hdr,
+                       goff, gpart, inst_pos);
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, hipStream_t s) {
     if (NB <= 0) return;
     hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
-    hipLaunchKernelGGL(k_sort_small, dim3(NB < 1024 ? NB : 1024), dim3(256), 0, s, NB, bin_offset, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 256 ? NB : 256), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

@@ -18,7 +18,8 @@
 //   point_list[cap] u32 sorted gaussian ids (what the compositing kernels walk)
 //   final_T[H*W], n_contrib[H*W]                         per-pixel state kept for the backward
 //   --- backward-only tail (a forward-only caller may pass a workspace without it) ---
-//   goff[P+1]      exclusive prefix of every Gaussian's bin-rect area (its slots in inst_pos)
+//   goff[P], gscan_part[P/1024+1]   exclusive prefix of every Gaussian's bin-rect area (its slots in inst_pos), kept as
+//                  (prefix inside its 1024-block, prefix of the blocks): both fall out of the forward for free
 //   inst_pos[cap]  for (Gaussian, k-th bin of its rect): position of that instance in point_list, or ~0
 //   inst_grad[cap] 48-byte records of per-INSTANCE partial sums {dcolor rgb, dmean2D xy | dconic xx xy yy, dopacity}
 //                  written with plain coalesced stores by the compositing backward and gathered per Gaussian by
@@ -218,21 +219,22 @@ struct GsrFwdParams {
     float *out_color;
     int *radii;
     int64_t cap;
-    unsigned dbg;  // development-only switches (flags >> 8): 1 = skip bin counting, 2 = skip splat stores
+    uint32_t *goff, *gpart;  // backward tail of the workspace (NULL for a forward-only workspace)
 };
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
-                     int64_t cap, GsrHeader *hdr, hipStream_t s);
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s);
+                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, hipStream_t s);
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+                        const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, hipStream_t s);
 void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
 void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
-                              const uint32_t *goff, uint32_t *inst_pos, GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s);
-void gsr_launch_gauss_scan(int P, const GsrSplat *splats, uint32_t *goff, uint32_t *part, hipStream_t s);
+                              const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, GsrGradAcc *inst_grad, const GsrHeader *hdr,
+                              hipStream_t s);
 struct GsrBwdParams {
     int P, W, H;
     const float *means3D, *scales, *rotations;
@@ -241,5 +243,5 @@ struct GsrBwdParams {
     const int *radii;
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dscales, *dL_drotations;
 };
-void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *inst_pos,
-                               const GsrGradAcc *inst_grad, hipStream_t s);
+void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
+                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, hipStream_t s);

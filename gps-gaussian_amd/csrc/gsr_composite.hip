@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
                                                        const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
-                                                       uint32_t *__restrict__ inst_pos, GsrGradAcc *__restrict__ inst_grad,
+                                                       const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos, GsrGradAcc *__restrict__ inst_grad,
                                                        const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sA[WAVES][WAVE];
     __shared__ float4 sB[WAVES][WAVE];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
         nC = c.x;
         const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
         const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-        nSlot = goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
+        nSlot = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
     };
     if ((int64_t)lane <= max_last - 1) stage(g.r0 + (uint32_t)(max_last - 1 - lane));
     for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
@@ -317,10 +317,10 @@ void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *spla
 
 void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
-                              const uint32_t *n_contrib, const uint32_t *goff, uint32_t *inst_pos, GsrGradAcc *inst_grad,
-                              const GsrHeader *hdr, hipStream_t s) {
+                              const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos,
+                              GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
     hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(64 * WAVES), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
-                       final_T, n_contrib, goff, inst_pos, inst_grad, hdr);
+                       final_T, n_contrib, goff, gpart, inst_pos, inst_grad, hdr);
 }

@@ -170,70 +170,36 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     dst[2] = make_float4(o2x, o2y, __uint_as_float(rlo), __uint_as_float(rhi));
     q.radii[i] = radius;
     }
+    if (q.goff) {  // training workspace: the slot prefix the backward needs (inst_pos slots = bin-rect cells) falls out here
+        __shared__ uint32_t s_w[GSR_BIN_THREADS / 64];
+        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        const int w = (int)(rhi & 0xffff) - (int)(rlo & 0xffff), h = (int)(rhi >> 16) - (int)(rlo >> 16);
+        const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
+        uint32_t x = area;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wid] = x;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < GSR_BIN_THREADS / 64; k++) {
+            const uint32_t v = s_w[k];
+            if (k < wid) woff += v;
+            tot += v;
+        }
+        if (i < q.P) q.goff[i] = woff + x - area;  // prefix inside this block of 1024 Gaussians
+        if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan_b turns these into the prefix of the blocks
+    }
     gsr_block_bin<false>(
         rlo, rhi, q.bx, [&](int x, int y) { return gsr_bin_hit(hit, x, y); }, [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {});
 }
 
-// exclusive prefix over Gaussians of their bin-rect area (= number of inst_pos slots); two-phase, 1024 per block
-__device__ __forceinline__ uint32_t rect_area(const GsrSplat *__restrict__ splats, int i, int P) {
-    if (i >= P) return 0u;
-    const float4 c = reinterpret_cast<const float4 *>(splats + i)[2];
-    const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
-    const int w = (int)(hi & 0xffff) - (int)(lo & 0xffff), h = (int)(hi >> 16) - (int)(lo >> 16);
-    return (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
-}
-__global__ __launch_bounds__(1024) void k_gscan_a(int P, const GsrSplat *__restrict__ splats, uint32_t *__restrict__ part) {
-    __shared__ uint32_t red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t v = rect_area(splats, blockIdx.x * 1024 + tid, P);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (lane == 0) red[wid] = v;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < 16; w++) t += red[w];
-        part[blockIdx.x] = t;
-    }
-}
-__global__ __launch_bounds__(1024) void k_gscan_b(int P, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ part,
-                                                  uint32_t *__restrict__ goff) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_pre;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t pre = 0;  // prefix of the preceding blocks' partials, summed cooperatively
-    for (int i = tid; i < (int)blockIdx.x; i += 1024) pre += part[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
-    if (lane == 0) wsum[wid] = pre;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < 16; w++) t += wsum[w];
-        s_pre = t;
-    }
-    __syncthreads();
-    const uint32_t base = s_pre;
-    const int i = blockIdx.x * 1024 + tid;
-    const uint32_t v = rect_area(splats, i, P);
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    __syncthreads();
-    if (lane == 63) wsum[wid] = x;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; w++) woff += wsum[w];
-    if (i < P) goff[i] = base + woff + x - v;
-    if (i == P - 1) goff[P] = base + woff + x;
-}
-
 __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrSplat *__restrict__ splats,
-                                                        const uint32_t *__restrict__ goff, const uint32_t *__restrict__ inst_pos,
-                                                        const GsrGradAcc *__restrict__ inst_grad) {
+                                                        const uint32_t *__restrict__ goff, const uint32_t *__restrict__ gpart,
+                                                        const uint32_t *__restrict__ inst_pos, const GsrGradAcc *__restrict__ inst_grad) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= q.P) return;
     float dm[3] = {0.f, 0.f, 0.f}, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -243,7 +209,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         // gather this Gaussian's instance records in rect order: fixed summation order -> reproducible gradients
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         float g2x = 0.f;
-        const uint32_t s0 = goff[i], s1 = goff[i + 1];
+        const float4 rc = reinterpret_cast<const float4 *>(splats + i)[2];
+        const uint32_t rlo = __float_as_uint(rc.z), rhi = __float_as_uint(rc.w);
+        const int rw = (int)(rhi & 0xffff) - (int)(rlo & 0xffff), rh = (int)(rhi >> 16) - (int)(rlo >> 16);
+        const uint32_t s0 = gpart[i >> 10] + goff[i], s1 = s0 + ((rw > 0 && rh > 0) ? (uint32_t)(rw * rh) : 0u);
         for (uint32_t sl = s0; sl < s1; sl += 4) {  // 4 slots per step: all position loads, then all record loads, then sum in order
             uint32_t pi[4];
 #pragma unroll
@@ -374,15 +343,8 @@ void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *bi
     hipLaunchKernelGGL(k_preprocess, dim3((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, p, splats, bin_count, hdr);
 }
 
-void gsr_launch_gauss_scan(int P, const GsrSplat *splats, uint32_t *goff, uint32_t *part, hipStream_t s) {
-    if (P <= 0) return;
-    const int nb = (P + 1023) / 1024;
-    hipLaunchKernelGGL(k_gscan_a, dim3(nb), dim3(1024), 0, s, P, splats, part);
-    hipLaunchKernelGGL(k_gscan_b, dim3(nb), dim3(1024), 0, s, P, splats, part, goff);
-}
-
-void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *inst_pos,
-                               const GsrGradAcc *inst_grad, hipStream_t s) {
+void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
+                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, goff, inst_pos, inst_grad);
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, goff, gpart, inst_pos, inst_grad);
 }

@@ -172,7 +172,7 @@ def test_config2_full_size_vs_oracle_and_properties():
 
 @pytest.mark.parametrize("n,expect_path", [(5000, "lds_small"), (24000, "lds_large"), (110000, "global")])
 def test_every_sort_path(n, expect_path):
-    """Tiny image, many large splats: per-tile lists of ~n (<=2048: 16 KiB LDS kernel; <=16384: 128 KiB LDS kernel; beyond: global)."""
+    """Tiny image, many large splats: per-bin lists of <=1024 (register sort, one wave), <=16384 (128 KiB LDS workgroup), beyond (global memory)."""
     import torch
     from gps_gaussian_amd import rasterizer as RZ
     from gps_gaussian_amd import synthetic as S
@@ -184,7 +184,7 @@ def test_every_sort_path(n, expect_path):
     st = RZ.export_state(t["ws"], n, 32, 32, t["cap"])
     rg = st["ranges"].cpu().numpy()
     longest = int((rg[:, 1] - rg[:, 0]).max())
-    assert {"lds_small": longest <= 2048, "lds_large": 2048 < longest <= 16384, "global": longest > 16384}[expect_path], longest
+    assert {"lds_small": longest <= 1024, "lds_large": 1024 < longest <= 16384, "global": longest > 16384}[expect_path], longest
     np.testing.assert_array_equal(radii, oradii)
     depth_bits = o.geom()["depth"].astype(np.float32).view(np.uint32).astype(np.int64)
     plist = st["point_list"].cpu().numpy().astype(np.int64)
