@@ -8,7 +8,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
-    "gsr_export_state", "gsr_timing_read", "cs_forward", "cs_backward",
+    "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "cs_forward",
+    "cs_backward",
 )
 
 GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
@@ -16,6 +17,10 @@ _ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch faile
 GSR_FLAG_DEBUG = 1
 GSR_FLAG_TIMING = 2
 STAGES = ("preprocess", "scan", "scatter", "sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
+
+
+class GsrStrided(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("batch_stride", C.c_int64), ("pixel_stride", C.c_int64), ("channel_stride", C.c_int64)]
 
 
 class GsrHeader(C.Structure):
@@ -58,6 +63,14 @@ def lib():
     l.gsr_export_state.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     l.gsr_timing_read.restype = i32
     l.gsr_timing_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    l.gsr_pack_scratch_bytes.restype = sz
+    l.gsr_pack_scratch_bytes.argtypes = [i32, i32, i32]
+    sp = C.POINTER(GsrStrided)
+    l.gsr_pack_views.restype = i32
+    l.gsr_pack_views.argtypes = [i32, i32, i32, sp, sp, sp, sp, sp, sp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    pp = C.POINTER(C.c_void_p)
+    l.gsr_pack_views_backward.restype = i32
+    l.gsr_pack_views_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, pp, pp, pp, pp, pp, vp]
     l.cs_forward.restype = i32
     l.cs_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     l.cs_backward.restype = i32

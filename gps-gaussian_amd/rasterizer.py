@@ -147,7 +147,7 @@ def _prep(t, name, shape_tail, device):
         t = t.float()
     if not t.is_contiguous():
         t = t.contiguous()
-    if t.data_ptr() % 16:
+    if shape_tail == (4,) and t.data_ptr() % 16:  # only the quaternions are read as float4 (row slices of packed buffers stay aligned)
         t = t.clone()
     if shape_tail is not None and (t.dim() < 1 or tuple(t.shape[1:]) != shape_tail):
         raise RuntimeError("%s must have dimensions (num_points, %s)" % (name, ", ".join(map(str, shape_tail))))

@@ -16,10 +16,8 @@
  *   cs_forward / cs_backward
  *       `corr_sampler.forward` / `corr_sampler.backward` of the external RAFT-Stereo sampler extension, called at
  *       core/corr.py:22 and core/corr.py:28.
- *   gsr_pack_views
+ *   gsr_pack_views / gsr_pack_views_backward
  *       the per-sample flatten + boolean-mask gather + concat + rgb affine of lib/GaussianRender.py:15-34.
- *   zsplat_forward
- *       the Taichi kernel TaichiRenderBatch.render_respective_color, lib/TaichiRender.py:13-24.
  */
 #ifndef GPSGS_H
 #define GPSGS_H
@@ -112,6 +110,30 @@ int gsr_timing_read(float *ms_sum_host, int *launches_host);
 int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, float *depth,
                      float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges, uint32_t *point_list,
                      float *final_T, uint32_t *n_contrib, void *stream);
+
+/* ---- fused mask-compaction + pack of the per-pixel Gaussian maps (lib/GaussianRender.py:15-34) -------------------------
+ * For every batch element b and view v (lmain, rmain): the pixels with valid != 0, in raster order, become consecutive
+ * rows; row order is sample, then view, then pixel -- exactly the order of the reference's mask-gathers + concats.
+ * rgb rows are img * 0.5 + 0.5.  All inputs are described with ELEMENT strides so that permuted views (the reference's xyz
+ * is one) need no copy: element (b, pixel, channel) = ptr[b*batch_stride + pixel*pixel_stride + channel*channel_stride].
+ * Outputs: packed rows out_xyz[rows,3], out_rgb[rows,3], out_rot[rows,4], out_scale[rows,3], out_opacity[rows] with capacity
+ * B*n_views*S2 rows; row_of_pixel[B,n_views,S2] (row index or ~0; kept for the backward); sample_offsets[B+1] (device):
+ * sample b owns rows [sample_offsets[b], sample_offsets[b+1]).  No host synchronisation. */
+typedef struct GsrStrided {
+    const void *ptr;
+    int64_t batch_stride, pixel_stride, channel_stride;
+} GsrStrided;
+
+size_t gsr_pack_scratch_bytes(int B, int n_views, int S2);
+int gsr_pack_views(int B, int n_views, int S2, const GsrStrided *valid /*u8*/, const GsrStrided *xyz, const GsrStrided *img,
+                   const GsrStrided *rot, const GsrStrided *scale, const GsrStrided *opacity /* host arrays [n_views] */,
+                   float *out_xyz, float *out_rgb, float *out_rot, float *out_scale, float *out_opacity, uint32_t *row_of_pixel,
+                   uint32_t *sample_offsets, uint32_t *scratch, void *stream);
+/* Backward: packed row gradients (any may be NULL = zero) -> planar map gradients, contiguous: d_xyz[v] is [B,S2,3], the
+ * others [B,C,S2]; host arrays of n_views device pointers, entries / arrays may be NULL (not wanted).  Invalid pixels get 0. */
+int gsr_pack_views_backward(int B, int n_views, int S2, const uint32_t *row_of_pixel, const float *g_xyz, const float *g_rgb,
+                            const float *g_rot, const float *g_scale, const float *g_opacity, float *const *d_xyz,
+                            float *const *d_img, float *const *d_rot, float *const *d_scale, float *const *d_opacity, void *stream);
 
 /* ---- 1-D correlation sampler ----------------------------------------------------------------------------------
  * volume[N,H1,W1,W2], coords[N,H1,W1] fp32 (channel 0 of the reference's [N,1,H1,W1]), out[N,2r+1,H1,W1].
