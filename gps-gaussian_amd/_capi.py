@@ -8,8 +8,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
-    "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "cs_forward",
-    "cs_backward",
+    "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
+    "fl_l1_ssim_forward", "fl_l1_ssim_backward", "cs_forward", "cs_backward",
 )
 
 GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
@@ -71,6 +71,12 @@ def lib():
     pp = C.POINTER(C.c_void_p)
     l.gsr_pack_views_backward.restype = i32
     l.gsr_pack_views_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, pp, pp, pp, pp, pp, vp]
+    l.fl_scratch_bytes.restype = sz
+    l.fl_scratch_bytes.argtypes = [i32, i32, i32]
+    l.fl_l1_ssim_forward.restype = i32
+    l.fl_l1_ssim_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    l.fl_l1_ssim_backward.restype = i32
+    l.fl_l1_ssim_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     l.cs_forward.restype = i32
     l.cs_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     l.cs_backward.restype = i32

@@ -1,0 +1,202 @@
+// fused_loss.hip -- fused L1 + SSIM loss, forward and backward, for gfx950.
+//
+// The step immediately after the rasteriser in stage-2 training: train_stage2.py:70-72 computes
+//     0.8 * l1_loss(pred, gt) + 0.2 * (1 - ssim(pred, gt))          on [B,3,2048,2048]
+// with /root/reference/lib/loss.py:36-83: ssim() = five depthwise 11x11 convolutions (zero padding, Gaussian window
+// sigma 1.5) + ~15 elementwise kernels, and autograd replays all of it backwards.  Here:
+//   k_loss_fwd   one 16x16 output tile per workgroup: the 26x26 halo of pred and gt is staged in LDS ONCE, the window is
+//                applied separably (11 + 11 taps instead of 121) to the five moments x1, x2, x1^2, x2^2, x1 x2, the SSIM
+//                map value and the three partial-derivative maps the backward needs are formed in registers, |x1 - x2|
+//                is added, and per-workgroup partial sums are written (deterministic two-level reduction, no atomics);
+//   k_loss_reduce  sums the partials in double -> {mean L1, mean SSIM};
+//   k_loss_bwd   same tiling: separable filter of the three derivative maps, then
+//                dL/dpred = gL1 * sign(x1 - x2) / N + gSSIM * (F*M1 + 2 x1 F*M2 + x2 F*M3) / N.
+// HBM traffic: forward reads 8 B and writes 12 B per element, backward reads 20 B and writes 4 B -- against roughly 30
+// full-tensor passes in the eager version.  The filter arithmetic is LDS-bandwidth bound (ds_read per tap).
+#include "gsr_common.h"
+
+namespace {
+
+constexpr int TS = 16, R = 5, HS = TS + 2 * R;  // tile side, window radius, halo side (26)
+
+struct Win {
+    float g[11];
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float *red /*[4]*/) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int tid = threadIdx.y * TS + threadIdx.x;
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_loss_fwd(const float *__restrict__ x1g, const float *__restrict__ x2g, int H, int W, Win win,
+                                                  float *__restrict__ m1, float *__restrict__ m2, float *__restrict__ m3,
+                                                  float2 *__restrict__ partial) {
+    __shared__ float t1[HS][HS + 1], t2[HS][HS + 1];
+    __shared__ float h[5][HS][TS + 1];
+    __shared__ float red[4];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TS + tx;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int i = tid; i < HS * HS; i += 256) {
+        const int ly = i / HS, lx = i - ly * HS, gy = y0 + ly - R, gx = x0 + lx - R;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        t1[ly][lx] = in ? x1g[plane + (size_t)gy * W + gx] : 0.f;  // zero padding, like conv2d(padding=5)
+        t2[ly][lx] = in ? x2g[plane + (size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * TS; i += 256) {  // horizontal pass: 26 rows x 16 columns
+        const int ly = i / TS, lx = i - ly * TS;
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.g[k], p = t1[ly][lx + k], q = t2[ly][lx + k];
+            a += w * p; b += w * q; aa += w * p * p; bb += w * q * q; ab += w * p * q;
+        }
+        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
+    }
+    __syncthreads();
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {  // vertical pass
+        const float w = win.g[k];
+        mu1 += w * h[0][ty + k][tx]; mu2 += w * h[1][ty + k][tx];
+        e11 += w * h[2][ty + k][tx]; e22 += w * h[3][ty + k][tx]; e12 += w * h[4][ty + k][tx];
+    }
+    const int gx = x0 + tx, gy = y0 + ty;
+    const bool in = gx < W && gy < H;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+    const float rB1 = 1.f / B1, rB2 = 1.f / B2;
+    const float smap = A1 * A2 * rB1 * rB2;
+    if (in && m1) {
+        const float ds_dmu1 = 2.f * mu2 * A2 * rB1 * rB2 - 2.f * mu1 * smap * rB1;
+        const float ds_ds1 = -smap * rB2;
+        const float ds_ds12 = 2.f * A1 * rB1 * rB2;
+        const size_t q = plane + (size_t)gy * W + gx;
+        m1[q] = ds_dmu1 - 2.f * mu1 * ds_ds1 - mu2 * ds_ds12;  // total derivative w.r.t. the filtered mean
+        m2[q] = ds_ds1;
+        m3[q] = ds_ds12;
+    }
+    const float l1v = in ? fabsf(t1[ty + R][tx + R] - t2[ty + R][tx + R]) : 0.f;
+    const float sv = in ? smap : 0.f;
+    const float sl = block_sum_256(l1v, red);
+    const float ss = block_sum_256(sv, red);
+    if (tid == 0) partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float2(sl, ss);
+}
+
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float2 *__restrict__ partial, int n, double inv_count, float *__restrict__ out2) {
+    __shared__ double r1[16], r2[16];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {  // fixed order per thread, fixed tree below: deterministic
+        const float2 p = partial[i];
+        a += (double)p.x;
+        b += (double)p.y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < 16; w++) { s1 += r1[w]; s2 += r2[w]; }
+        out2[0] = (float)(s1 * inv_count);
+        out2[1] = (float)(s2 * inv_count);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_loss_bwd(const float *__restrict__ x1g, const float *__restrict__ x2g, const float *__restrict__ m1,
+                                                  const float *__restrict__ m2, const float *__restrict__ m3, int H, int W, Win win,
+                                                  const float *__restrict__ g_out2 /* d/dL1mean, d/dSSIMmean (device) */, float inv_count,
+                                                  float *__restrict__ dx1) {
+    __shared__ float t[3][HS][HS + 1];
+    __shared__ float h[3][HS][TS + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TS + tx;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int i = tid; i < HS * HS; i += 256) {
+        const int ly = i / HS, lx = i - ly * HS, gy = y0 + ly - R, gx = x0 + lx - R;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t q = plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+        t[0][ly][lx] = in ? m1[q] : 0.f;
+        t[1][ly][lx] = in ? m2[q] : 0.f;
+        t[2][ly][lx] = in ? m3[q] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * TS; i += 256) {
+        const int ly = i / TS, lx = i - ly * TS;
+        float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.g[k];
+            a += w * t[0][ly][lx + k]; b += w * t[1][ly][lx + k]; c += w * t[2][ly][lx + k];
+        }
+        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = c;
+    }
+    __syncthreads();
+    float f1 = 0.f, f2 = 0.f, f3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const float w = win.g[k];
+        f1 += w * h[0][ty + k][tx]; f2 += w * h[1][ty + k][tx]; f3 += w * h[2][ty + k][tx];
+    }
+    const int gx = x0 + tx, gy = y0 + ty;
+    if (gx < W && gy < H) {
+        const size_t q = plane + (size_t)gy * W + gx;
+        const float a = x1g[q], b = x2g[q];
+        const float d = a - b;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // torch.abs backward: sign(0) = 0
+        dx1[q] = (g_out2[0] * sgn + g_out2[1] * (f1 + 2.f * a * f2 + b * f3)) * inv_count;
+    }
+}
+
+Win make_window() {  // lib/loss.py:40-42: exp(-(x-5)^2 / (2 * 1.5^2)), normalised in fp32
+    Win w;
+    float g[11], s = 0.f;
+    for (int x = 0; x < 11; x++) {
+        g[x] = (float)exp(-(double)((x - 5) * (x - 5)) / (2.0 * 1.5 * 1.5));
+        s += g[x];
+    }
+    for (int x = 0; x < 11; x++) w.g[x] = g[x] / s;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t fl_scratch_bytes(int planes, int H, int W) {
+    if (planes < 0 || H < 0 || W < 0) return 0;
+    return (size_t)planes * ((H + TS - 1) / TS) * ((W + TS - 1) / TS) * sizeof(float2) + 16;
+}
+
+extern "C" int fl_l1_ssim_forward(const float *pred, const float *gt, int planes, int H, int W, float *m1, float *m2, float *m3,
+                                  void *scratch, float *out2, void *stream) {
+    if (planes < 0 || H < 0 || W < 0) return GPSGS_E_INVALID;
+    if ((size_t)planes * H * W == 0) return GPSGS_E_INVALID;  // a mean over nothing is undefined (torch returns nan)
+    if (!pred || !gt || !scratch || !out2) return GPSGS_E_INVALID;
+    if ((m1 || m2 || m3) && !(m1 && m2 && m3)) return GPSGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    hipLaunchKernelGGL(k_loss_fwd, grid, dim3(TS, TS), 0, s, pred, gt, H, W, make_window(), m1, m2, m3, (float2 *)scratch);
+    const int n = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, (const float2 *)scratch, n, 1.0 / ((double)planes * H * W), out2);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
+extern "C" int fl_l1_ssim_backward(const float *pred, const float *gt, const float *m1, const float *m2, const float *m3, int planes, int H,
+                                   int W, const float *grad_out2, float *d_pred, void *stream) {
+    if (planes < 0 || H < 0 || W < 0) return GPSGS_E_INVALID;
+    if ((size_t)planes * H * W == 0) return GPSGS_OK;
+    if (!pred || !gt || !m1 || !m2 || !m3 || !grad_out2 || !d_pred) return GPSGS_E_INVALID;
+    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    hipLaunchKernelGGL(k_loss_bwd, grid, dim3(TS, TS), 0, (hipStream_t)stream, pred, gt, m1, m2, m3, H, W, make_window(), grad_out2,
+                       (float)(1.0 / ((double)planes * H * W)), d_pred);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}

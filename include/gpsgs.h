@@ -18,6 +18,8 @@
  *       core/corr.py:22 and core/corr.py:28.
  *   gsr_pack_views / gsr_pack_views_backward
  *       the per-sample flatten + boolean-mask gather + concat + rgb affine of lib/GaussianRender.py:15-34.
+ *   fl_l1_ssim_forward / fl_l1_ssim_backward
+ *       l1_loss + ssim of lib/loss.py:36-83 (and their autograd backward), called at train_stage2.py:70-72.
  */
 #ifndef GPSGS_H
 #define GPSGS_H
@@ -134,6 +136,16 @@ int gsr_pack_views(int B, int n_views, int S2, const GsrStrided *valid /*u8*/, c
 int gsr_pack_views_backward(int B, int n_views, int S2, const uint32_t *row_of_pixel, const float *g_xyz, const float *g_rgb,
                             const float *g_rot, const float *g_scale, const float *g_opacity, float *const *d_xyz,
                             float *const *d_img, float *const *d_rot, float *const *d_scale, float *const *d_opacity, void *stream);
+
+/* ---- fused L1 + SSIM loss (lib/loss.py:36-83 as used at train_stage2.py:70-72) ------------------------------------------
+ * pred, gt: contiguous fp32 [planes = B*C, H, W].  out2 (device) = {mean |pred - gt|, mean SSIM map} (11x11 Gaussian window,
+ * sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2).  m1,m2,m3 [planes,H,W]: derivative maps kept for the backward (all three
+ * or none).  scratch: fl_scratch_bytes().  Backward: grad_out2 (device) = {dL/d(mean L1), dL/d(mean SSIM)}; writes d_pred. */
+size_t fl_scratch_bytes(int planes, int H, int W);
+int fl_l1_ssim_forward(const float *pred, const float *gt, int planes, int H, int W, float *m1, float *m2, float *m3, void *scratch,
+                       float *out2, void *stream);
+int fl_l1_ssim_backward(const float *pred, const float *gt, const float *m1, const float *m2, const float *m3, int planes, int H, int W,
+                        const float *grad_out2, float *d_pred, void *stream);
 
 /* ---- 1-D correlation sampler ----------------------------------------------------------------------------------
  * volume[N,H1,W1,W2], coords[N,H1,W1] fp32 (channel 0 of the reference's [N,1,H1,W1]), out[N,2r+1,H1,W1].

@@ -114,3 +114,17 @@ for i, c in enumerate(captured):
         pk["out%d_%s" % (i, k)] = v
 np.savez_compressed(os.path.join(HERE, "pts2render_golden.npz"), **pk)
 print("golden fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
+
+# ---- L1 + SSIM loss (row f2) ---------------------------------------------------------------------------------------
+from lib.loss import l1_loss, ssim  # noqa: E402
+
+torch.manual_seed(77)
+pred = torch.rand(2, 3, 37, 45, requires_grad=True)
+gt = (pred.detach() + 0.15 * torch.randn(2, 3, 37, 45)).clamp(0, 1)
+l1 = l1_loss(pred, gt)
+ss = ssim(pred, gt)
+g_l1, = torch.autograd.grad(l1, pred, retain_graph=True)
+g_ss, = torch.autograd.grad(ss, pred)
+np.savez_compressed(os.path.join(HERE, "loss_golden.npz"), pred=pred.detach().numpy(), gt=gt.numpy(), l1=l1.item(), ssim=ss.item(),
+                    grad_l1=g_l1.numpy(), grad_ssim=g_ss.numpy())
+print("loss golden: l1 %.6f ssim %.6f" % (l1.item(), ss.item()))

@@ -84,3 +84,14 @@ def test_zsplat_oracle_sequential_semantics():
     assert depth[0, 3, 2] == np.float32(0.8) and tuple(color[0, :, 3, 2]) == (0, 0, 1)   # nearest wins; later tie wins
     assert depth[0, 7, 0] == np.float32(0.1) and tuple(color[0, :, 7, 0]) == (1, 1, 1)   # clamped to the border
     assert depth[0, 4, 4] == 0 and tuple(color[0, :, 4, 4]) == (-1, -1, -1)              # masked point ignored
+
+
+def test_loss_oracle_matches_reference_l1_and_ssim_values_and_gradients():
+    """oracle/loss_oracle.py (fp64 numpy) vs values/gradients produced by the reference's own lib/loss.py."""
+    from oracle import loss_oracle as L
+    g = np.load(os.path.join(GOLDEN, "loss_golden.npz"))
+    s, gr = L.ssim(g["pred"], g["gt"], with_grad=True)
+    assert abs(L.l1(g["pred"], g["gt"]) - float(g["l1"])) < 1e-7
+    assert abs(s - float(g["ssim"])) < 1e-6
+    np.testing.assert_allclose(gr, g["grad_ssim"], rtol=0, atol=1e-5 * np.abs(g["grad_ssim"]).max())
+    np.testing.assert_allclose(np.sign(g["pred"].astype(np.float64) - g["gt"]) / g["pred"].size, g["grad_l1"], atol=1e-9)
