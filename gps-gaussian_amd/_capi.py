@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
-    "fl_l1_ssim_forward", "fl_l1_ssim_backward", "cs_forward", "cs_backward",
+    "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
 )
 
 GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
@@ -77,6 +77,10 @@ def lib():
     l.fl_l1_ssim_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     l.fl_l1_ssim_backward.restype = i32
     l.fl_l1_ssim_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    l.up_unproject_forward.restype = i32
+    l.up_unproject_forward.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    l.up_unproject_backward.restype = i32
+    l.up_unproject_backward.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]
     l.cs_forward.restype = i32
     l.cs_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     l.cs_backward.restype = i32

@@ -18,6 +18,8 @@
  *       core/corr.py:22 and core/corr.py:28.
  *   gsr_pack_views / gsr_pack_views_backward
  *       the per-sample flatten + boolean-mask gather + concat + rgb affine of lib/GaussianRender.py:15-34.
+ *   up_unproject_forward / up_unproject_backward
+ *       flow2depth + depth2pc + the validity test: lib/utils.py:113-120, :88-110, lib/network.py:66-69.
  *   fl_l1_ssim_forward / fl_l1_ssim_backward
  *       l1_loss + ssim of lib/loss.py:36-83 (and their autograd backward), called at train_stage2.py:70-72.
  */
@@ -146,6 +148,18 @@ int fl_l1_ssim_forward(const float *pred, const float *gt, int planes, int H, in
                        float *out2, void *stream);
 int fl_l1_ssim_backward(const float *pred, const float *gt, const float *m1, const float *m2, const float *m3, int planes, int H, int W,
                         const float *grad_out2, float *d_pred, void *stream);
+
+/* ---- fused disparity -> inverse depth -> world points (lib/utils.py:88-120, lib/network.py:66-69) ---------------------
+ * flow [B,1,S,S], mask channel 0 of [B,C,S,S] (mask_batch_stride = C*S*S elements), camera parameters on the HOST:
+ * ref_intr/intr [B,3,3], extr [B,3,4] row-major, Tf_x [B]; B <= 16.  Outputs depth [B,1,S,S] (inverse depth), xyz [B,S*S,3],
+ * valid [B,S*S] (u8).  Backward: g_depth [B,1,S,S] and/or g_xyz (element strides given; either may be NULL) -> d_flow. */
+int up_unproject_forward(int B, int S, const float *flow, const float *mask, int64_t mask_batch_stride, const float *ref_intr_host,
+                         const float *intr_host, const float *extr_host, const float *tf_host, float *depth, float *xyz,
+                         uint8_t *valid, void *stream);
+int up_unproject_backward(int B, int S, const float *depth, const float *mask, int64_t mask_batch_stride, const float *ref_intr_host,
+                          const float *intr_host, const float *extr_host, const float *tf_host, const float *g_depth,
+                          const float *g_xyz, int64_t gx_batch_stride, int64_t gx_pixel_stride, int64_t gx_channel_stride,
+                          float *d_flow, void *stream);
 
 /* ---- 1-D correlation sampler ----------------------------------------------------------------------------------
  * volume[N,H1,W1,W2], coords[N,H1,W1] fp32 (channel 0 of the reference's [N,1,H1,W1]), out[N,2r+1,H1,W1].

@@ -128,3 +128,26 @@ g_ss, = torch.autograd.grad(ss, pred)
 np.savez_compressed(os.path.join(HERE, "loss_golden.npz"), pred=pred.detach().numpy(), gt=gt.numpy(), l1=l1.item(), ssim=ss.item(),
                     grad_l1=g_l1.numpy(), grad_ssim=g_ss.numpy())
 print("loss golden: l1 %.6f ssim %.6f" % (l1.item(), ss.item()))
+
+# ---- flow2depth + depth2pc (row f3) ---------------------------------------------------------------------------------
+from lib.utils import flow2depth  # noqa: E402
+
+torch.manual_seed(11)
+Bu, Su = 2, 20
+ku = torch.from_numpy(i0.copy()); ku[:2] *= Su / res
+intr_u = torch.stack([ku, ku * torch.tensor([[1.0, 1, 1.01], [1, 1, 1], [1, 1, 1]])])
+ref_intr_u = intr_u.clone(); ref_intr_u[:, 0, 2] += torch.tensor([0.7, -0.4])
+extr_u = torch.stack([torch.from_numpy(e0), torch.from_numpy(e1)])
+flow_u = (torch.rand(Bu, 1, Su, Su) * 3 + 1.5).requires_grad_(True)
+mask_u = (torch.rand(Bu, 3, Su, Su) > 0.3).float()
+Tf_u = torch.tensor([-6.5, -7.25])
+du = {"ref_intr": ref_intr_u, "intr": intr_u, "flow_pred": flow_u, "Tf_x": Tf_u, "mask": mask_u}
+depth_u = flow2depth(du)
+xyz_u = depth2pc(depth_u, extr_u, intr_u)
+gd, gx = torch.randn_like(depth_u), torch.randn_like(xyz_u)
+gflow, = torch.autograd.grad((depth_u * gd).sum() + (xyz_u * gx).sum(), flow_u)
+np.savez_compressed(os.path.join(HERE, "unproject_golden.npz"), ref_intr=ref_intr_u.numpy(), intr=intr_u.numpy(), extr=extr_u.numpy(),
+                    flow=flow_u.detach().numpy(), mask=mask_u.numpy(), Tf_x=Tf_u.numpy(), depth=depth_u.detach().numpy(),
+                    xyz=xyz_u.detach().numpy(), valid=(depth_u != 0).view(Bu, -1).numpy(), g_depth=gd.numpy(), g_xyz=gx.numpy(),
+                    g_flow=gflow.numpy())
+print("unproject golden written")
