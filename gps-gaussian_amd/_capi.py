@@ -25,7 +25,7 @@ class GsrStrided(C.Structure):
 
 class GsrHeader(C.Structure):
     _fields_ = [("num_rendered", C.c_uint64), ("overflow", C.c_uint32), ("max_tile_count", C.c_uint32),
-                ("num_busy_wgs", C.c_uint32), ("reserved", C.c_uint32 * 11)]
+                ("num_busy_wgs", C.c_uint32), ("num_slots", C.c_uint32), ("reserved", C.c_uint32 * 10)]
 
 
 _lib = None

@@ -215,7 +215,7 @@ extern "C" int gsr_timing_read(float *ms_sum_host, int *launches_host) {
 
 extern "C" int gsr_copy_header_async(const void *workspace, void *host_pinned_out, void *stream) {
     if (!workspace || !host_pinned_out) return GPSGS_E_INVALID;
-    return hipMemcpyAsync(host_pinned_out, workspace, 16, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+    return hipMemcpyAsync(host_pinned_out, workspace, 32, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
 }
 
 extern "C" int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream) {

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         const uint32_t nbusy_before = pre_busy + bpos;
         wg_order[busy ? nbusy_before : tot_busy + (w - nbusy_before)] = w;
     }
+    uint32_t tot_slots = 0;
     if (blockIdx.x == 0 && gpart) {  // training: block sums of the per-Gaussian slot counts -> exclusive prefix, in place
         uint32_t carry = 0;
         for (int base = 0; base < n_gblocks; base += SB) {
@@ -108,13 +109,15 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
             if (k < n_gblocks) gpart[k] = carry + ex;
             carry += tot;
         }
+        tot_slots = carry;  // inst_pos needs one slot per bin-rect cell (>= R: exact culling only removes instances)
     }
     if (blockIdx.x == 0 && tid == 0) {
         bin_offset[NB] = tot_sum;
         hdr->num_rendered = tot_sum;
-        hdr->overflow = ((int64_t)tot_sum > cap) ? 1u : 0u;
+        hdr->overflow = ((int64_t)tot_sum > cap || (int64_t)tot_slots > cap) ? 1u : 0u;
         hdr->max_tile_count = tot_max;
         hdr->num_busy_wgs = tot_busy;
+        hdr->num_slots = tot_slots;
     }
 }
 

@@ -87,8 +87,8 @@ def _drain_pending(st, block=False):
         if block:
             ev.synchronize()
         if ev.query():
-            R, overflow = int(hdr[0]), int(hdr[1]) & 0xffffffff
-            _learn(st, R, P)
+            R, overflow, need = _decode(hdr)
+            _learn(st, R, need, P)
             if overflow:
                 st["pending"] = []
                 raise RuntimeError(
@@ -99,11 +99,19 @@ def _drain_pending(st, block=False):
     st["pending"] = keep
 
 
-def _learn(st, R, P):
+def _decode(hdr):
+    """hdr: int64[4] view of the first 32 header bytes -> (R, overflow, capacity needed = max(R, inst_pos slots))."""
+    R = int(hdr[0])
+    overflow = int(hdr[1]) & 0xffffffff
+    slots = (int(hdr[2]) >> 32) & 0xffffffff
+    return R, overflow, max(R, slots)
+
+
+def _learn(st, R, need, P):
     st["last_R"] = R
     if P > 0:
-        st["ratio"] = max(st["ratio"], R / P)
-    st["floor"] = max(st["floor"], min(int(R * 1.25) + 4096, 0x7fffffff))
+        st["ratio"] = max(st["ratio"], need / P)
+    st["floor"] = max(st["floor"], min(int(need * 1.25) + 4096, 0x7fffffff))
 
 
 def _ptr(t):
@@ -114,7 +122,7 @@ class _HeaderRing:
     """Pinned 16-byte header slots + reusable events (allocating pinned memory / events per call costs tens of us)."""
 
     def __init__(self, n=64):
-        self.buf = torch.zeros((n, 2), dtype=torch.int64).pin_memory()
+        self.buf = torch.zeros((n, 4), dtype=torch.int64).pin_memory()  # 32-byte header prefix per slot
         self.np = self.buf.numpy()  # same memory; plain numpy scalars are much cheaper to read than 0-d tensors
         self.base = self.buf.data_ptr()
         self.events = [torch.cuda.Event() for _ in range(n)]
@@ -123,7 +131,7 @@ class _HeaderRing:
     def next(self):
         i = self.i
         self.i = (i + 1) % self.n
-        return self.np[i], C.c_void_p(self.base + 16 * i), self.events[i]
+        return self.np[i], C.c_void_p(self.base + 32 * i), self.events[i]
 
 
 _rings = {}
@@ -232,8 +240,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                     st["pending"].append((ev, hdr, P))
                     break
                 ev.synchronize()
-                R, overflow = int(hdr[0]), int(hdr[1]) & 0xffffffff
-                _learn(st, R, P)
+                R, overflow, need = _decode(hdr)
+                _learn(st, R, need, P)
                 if not overflow:
                     break
                 cap = _capacity_for(st, P)  # grown by _learn; re-run the whole (cheap) forward

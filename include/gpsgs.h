@@ -64,14 +64,15 @@ const char *gpsgs_build_info(void); /* "gfx950 <compiler> <date>" */
  * forward never reads it back.  Instead the header records the R that was needed and an overflow flag:
  *   - overflow == 0: results are exact;
  *   - overflow != 0: NOTHING was rendered (out_color untouched apart from zero fill); the caller must re-run with
- *     instance_capacity >= the reported R.  (Upstream sizes the buffer with a blocking D2H read of R on every call.)
+ *     instance_capacity >= max(num_rendered, num_slots) as reported.  (Upstream sizes the buffer with a blocking D2H read of R on every call.)
  */
 typedef struct GsrHeader {      /* first bytes of the workspace, device memory */
     uint64_t num_rendered;      /* R needed by the last gsr_forward */
-    uint32_t overflow;          /* 1 if R > instance_capacity */
+    uint32_t overflow;          /* 1 if R (or, with a backward tail, num_slots) > instance_capacity */
     uint32_t max_tile_count;    /* longest per-bin list (one 8x8-pixel bin = one wave64 work item) */
-    uint32_t num_busy_wgs;      /* compositing workgroups (4 bins each) with a non-empty list; they are scheduled first */
-    uint32_t reserved[11];
+    uint32_t num_busy_wgs;      /* bins with a non-empty list; they are scheduled first */
+    uint32_t num_slots;         /* training workspaces only: bin-rect cells of all Gaussians (inst_pos slots); also <= capacity */
+    uint32_t reserved[10];
 } GsrHeader;
 
 size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity);              /* forward + backward */
@@ -95,7 +96,7 @@ int gsr_backward(int P, int width, int height, const float *means3D, const float
                  float *dL_dopacity, float *dL_dscales, float *dL_drotations, void *workspace,
                  size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream);
 
-/* Enqueues a copy of the first 16 header bytes {u64 num_rendered, u32 overflow, u32 max_bin_count} to PINNED host memory on
+/* Enqueues a copy of the first 32 header bytes {u64 num_rendered, u32 overflow, max_bin_count, num_busy, num_slots, 2 pad} to PINNED host memory on
  * `stream`; does not synchronise (the host reads it after an event / stream sync of its own). */
 int gsr_copy_header_async(const void *workspace, void *host_pinned_out, void *stream);
 

@@ -1,0 +1,84 @@
+// Torch-free host for the C-ABI (include/gpsgs.h): what a C/C++ integrator of the render path writes.
+// Build: hipcc --offload-arch=gfx950 tests/capi_host/capi_host_smoke.cpp -Iinclude -Lgps-gaussian_amd/lib -lgpsgs_hip -o <out>
+// Renders a few hundred Gaussians forward + backward, re-runs after a deliberate capacity overflow, checks basic invariants
+// and prints "CAPI_HOST_OK".  (Numerical parity is the job of the Python GPU tests; this proves the boundary stands alone.)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gpsgs.h"
+
+#define CK(x) do { if ((x) != hipSuccess) { printf("HIP error line %d\n", __LINE__); return 1; } } while (0)
+
+template <typename T> static T *dev(const std::vector<T> &h) {
+    T *d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(T) + 16) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+
+int main() {
+    const int P = 400, W = 100, H = 70;
+    const float fx = 90.f;
+    std::vector<float> m(3 * P), c(3 * P), o(P), s(3 * P), r(4 * P);
+    srand(7);
+    auto U = []() { return (float)rand() / (float)RAND_MAX; };
+    for (int i = 0; i < P; i++) {
+        m[3 * i] = (U() - 0.5f) * 2.0f; m[3 * i + 1] = (U() - 0.5f) * 1.4f; m[3 * i + 2] = 1.5f + 2.f * U();
+        for (int k = 0; k < 3; k++) { c[3 * i + k] = U(); s[3 * i + k] = 0.01f + 0.05f * U(); }
+        o[i] = 0.2f + 0.7f * U();
+        float q[4] = {U() - .5f, U() - .5f, U() - .5f, U() - .5f}, n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int k = 0; k < 4; k++) r[4 * i + k] = q[k] / n;
+    }
+    // identity view; projection of lib/graphics_utils.py:31-48 (transposed -> flat column-major), znear 0.01, zfar 100
+    std::vector<float> view(16, 0.f), proj(16, 0.f), bg = {0.1f, 0.2f, 0.3f};
+    for (int i = 0; i < 4; i++) view[i * 4 + i] = 1.f;
+    const float cx = W / 2.f, cy = H / 2.f, zn = 0.01f, zf = 100.f;
+    // P[0][0]=2fx/W, P[1][1]=2fy/H, P[0][2]=(2cx-W)/W, P[1][2]=(2cy-H)/H, P[3][2]=1, P[2][2]=zf/(zf-zn), P[2][3]=-zf zn/(zf-zn); flat[col*4+row]
+    proj[0 * 4 + 0] = 2 * fx / W; proj[1 * 4 + 1] = 2 * fx / H; proj[2 * 4 + 0] = (2 * cx - W) / W; proj[2 * 4 + 1] = (2 * cy - H) / H;
+    proj[2 * 4 + 3] = 1.f; proj[2 * 4 + 2] = zf / (zf - zn); proj[3 * 4 + 2] = -zf * zn / (zf - zn);
+    float *dm = dev(m), *dc = dev(c), *dop = dev(o), *ds = dev(s), *dr = dev(r), *dv = dev(view), *dp = dev(proj), *dbg = dev(bg);
+    float *color; int *radii;
+    CK(hipMalloc(&color, sizeof(float) * 3 * W * H)); CK(hipMalloc(&radii, sizeof(int) * P));
+    hipStream_t st; CK(hipStreamCreate(&st));
+
+    GsrHeader h;
+    void *ws = nullptr; size_t nbytes = 0; int64_t cap = 16;  // far too small on purpose
+    for (int attempt = 0; attempt < 2; attempt++) {
+        nbytes = gsr_workspace_bytes(P, W, H, cap);
+        if (ws) (void)hipFree(ws);
+        CK(hipMalloc(&ws, nbytes));
+        int rc = gsr_forward(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color, radii, ws, nbytes, cap, 0, st);
+        if (rc != GPSGS_OK) { printf("gsr_forward rc=%d\n", rc); return 1; }
+        if (gsr_read_header(ws, &h, st) != GPSGS_OK) return 1;
+        if (attempt == 0) {
+            if (!h.overflow) { printf("expected an overflow with capacity 16\n"); return 1; }
+            cap = (int64_t)(h.num_rendered > h.num_slots ? h.num_rendered : h.num_slots) + 8;  // the header says how much was needed
+        }
+    }
+    if (h.overflow || h.num_rendered == 0) { printf("second attempt: overflow=%u R=%llu\n", h.overflow, (unsigned long long)h.num_rendered); return 1; }
+    std::vector<float> img(3 * W * H);
+    CK(hipMemcpy(img.data(), color, img.size() * 4, hipMemcpyDeviceToHost));
+    double sum = 0; for (float v : img) { if (!std::isfinite(v)) { printf("non-finite pixel\n"); return 1; } sum += v; }
+    if (!(sum > 0.1 * W * H)) { printf("image looks empty: %f\n", sum); return 1; }
+
+    std::vector<float> gpix(3 * W * H, 1.0f);
+    float *dgp = dev(gpix), *g3, *g2, *gc, *go, *gs, *gr;
+    CK(hipMalloc(&g3, 12 * P)); CK(hipMalloc(&g2, 12 * P)); CK(hipMalloc(&gc, 12 * P)); CK(hipMalloc(&go, 4 * P)); CK(hipMalloc(&gs, 12 * P)); CK(hipMalloc(&gr, 16 * P));
+    int rc = gsr_backward(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, radii, dgp, g3, g2, gc, go, gs, gr, ws, nbytes, cap, 0, st);
+    if (rc != GPSGS_OK) { printf("gsr_backward rc=%d\n", rc); return 1; }
+    CK(hipStreamSynchronize(st));
+    std::vector<float> hgc(3 * P);
+    CK(hipMemcpy(hgc.data(), gc, 12 * P, hipMemcpyDeviceToHost));
+    // d(sum of pixels)/d colour = sum over pixels of alpha*T >= 0, and > 0 for every Gaussian that was drawn
+    double gsum = 0; for (float v : hgc) { if (!(v >= 0.f) || !std::isfinite(v)) { printf("bad colour gradient %f\n", v); return 1; } gsum += v; }
+    if (!(gsum > 0)) { printf("zero gradient\n"); return 1; }
+    // argument checking happens before any launch
+    if (gsr_forward(P, 0, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, nbytes, cap, 0, st) != GPSGS_E_INVALID) return 1;
+    if (gsr_forward(P, W, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, 64, cap, 0, st) != GPSGS_E_WORKSPACE) return 1;
+    printf("CAPI_HOST_OK R=%llu longest_bin=%u image_sum=%.3f grad_sum=%.3f\n", (unsigned long long)h.num_rendered, h.max_tile_count, sum, gsum);
+    return 0;
+}

@@ -220,6 +220,31 @@ def test_capacity_overflow_is_detected_and_repaired(monkeypatch):
     assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
 
 
+def test_capacity_between_instances_and_slots_is_an_overflow(monkeypatch):
+    """The backward's inst_pos table needs one slot per bin-rect CELL, which exceeds the number of listed instances once
+    exact culling drops cells.  A capacity of R + 8 must therefore be reported as an overflow for a training workspace
+    (found by the torch-free C++ host test) and be repaired transparently."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_scene(256, 30000)
+    dpix = np.ones((3, 256, 256), np.float32)
+    _, _, g_ref, _ = hip_render(g, dpix)
+    R = RZ.last_stats(torch.device("cuda:0"))["last_R"]
+    calls = []
+    real = RZ._capacity_for
+
+    def tight_first(st, P):
+        calls.append(1)
+        return R + 8 if len(calls) == 1 else real(st, P)
+
+    monkeypatch.setattr(RZ, "_capacity_for", tight_first)
+    _, _, g_new, _ = hip_render(g, dpix)
+    assert len(calls) >= 2                      # R + 8 < number of slots -> overflow -> re-run
+    for k in g_ref:
+        np.testing.assert_array_equal(g_new[k], g_ref[k])
+
+
 def test_deferred_check_mode(monkeypatch):
     import torch
     from gps_gaussian_amd import rasterizer as RZ
