@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
-    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
+    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
 )
@@ -52,6 +52,8 @@ def lib():
     l.gsr_workspace_bytes_forward_only.argtypes = [i32, i32, i32, i64]
     l.gsr_forward.restype = i32
     l.gsr_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, sz, i64, u32, vp]
+    l.gsr_forward_notify.restype = i32
+    l.gsr_forward_notify.argtypes = l.gsr_forward.argtypes + [vp, u32]
     l.gsr_backward.restype = i32
     l.gsr_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                vp, vp, sz, i64, u32, vp]

@@ -80,10 +80,11 @@ extern "C" size_t gsr_workspace_bytes_forward_only(int P, int width, int height,
     return gsr_layout(P, width, height, instance_capacity).total_fwd;
 }
 
-extern "C" int gsr_forward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
-                           const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
-                           const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
-                           void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream) {
+extern "C" int gsr_forward_notify(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                                  const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                                  const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                                  void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream,
+                                  void *host_header_out, uint32_t notify_seq) {
     if (P < 0 || width <= 0 || height <= 0 || instance_capacity < 0 || instance_capacity > 0x7fffffffLL) return GPSGS_E_INVALID;
     if (width > 65535 * GSR_TILE || height > 65535 * GSR_TILE) return GPSGS_E_INVALID;
     if (!out_color || !workspace) return GPSGS_E_INVALID;
@@ -92,6 +93,15 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
     if (workspace_bytes < L.total_fwd) return GPSGS_E_WORKSPACE;  // the backward tail is optional for a forward
     hipStream_t s = (hipStream_t)stream;
+    uint32_t *host_hdr = nullptr;
+    if (host_header_out) {  // must be pinned (hipHostMalloc / hipHostRegister) memory the device can write
+        void *dptr = nullptr;
+        if (notify_seq == 0 || hipHostGetDevicePointer(&dptr, host_header_out, 0) != hipSuccess || !dptr) {
+            (void)hipGetLastError();
+            return GPSGS_E_INVALID;
+        }
+        host_hdr = static_cast<uint32_t *>(dptr);
+    }
     GsrHeader *hdr = reinterpret_cast<GsrHeader *>(at(workspace, L.header));
     uint32_t *bin_count = reinterpret_cast<uint32_t *>(at(workspace, L.bin_count));
     uint32_t *bin_offset = reinterpret_cast<uint32_t *>(at(workspace, L.bin_offset));
@@ -131,7 +141,7 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCAN, s);
-        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, q.gpart, n_gblocks, s);
+        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
@@ -149,6 +159,14 @@ extern "C" int gsr_forward(int P, int width, int height, const float *means3D, c
         gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
     }
     return check(s, flags);
+}
+
+extern "C" int gsr_forward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                           const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                           const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                           void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream) {
+    return gsr_forward_notify(P, width, height, means3D, colors, opacities, scales, rotations, scale_modifier, tanfovx, tanfovy, viewmatrix,
+                              projmatrix, bg, out_color, radii, workspace, workspace_bytes, instance_capacity, flags, stream, nullptr, 0u);
 }
 
 extern "C" int gsr_backward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_
 __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, const uint4 *__restrict__ part,
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
                                                uint32_t *__restrict__ wg_order, int NB, int nblocks, int64_t cap,
-                                               GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks) {
+                                               GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
+                                               uint32_t *__restrict__ host_hdr, uint32_t host_seq) {
     __shared__ uint32_t wsum[SB / 64];
     const int tid = threadIdx.x;
     uint32_t pre_sum = 0, pre_busy = 0, tot_sum = 0, tot_busy = 0, tot_max = 0;
@@ -118,6 +119,15 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         hdr->max_tile_count = tot_max;
         hdr->num_busy_wgs = tot_busy;
         hdr->num_slots = tot_slots;
+        if (host_hdr) {
+            // early notification: the header goes straight to host-coherent pinned memory from here, so the host can check
+            // capacity while scatter / sort / compositing are still running (no copy engine, no event in the stream)
+            const uint32_t ovf = ((int64_t)tot_sum > cap || (int64_t)tot_slots > cap) ? 1u : 0u;
+            volatile uint32_t *h = host_hdr;
+            h[0] = tot_sum; h[1] = 0u; h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = 0u;
+            __threadfence_system();
+            __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this word
+        }
     }
 }
 
@@ -319,11 +329,11 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 }  // namespace
 
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
-                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, hipStream_t s) {
+                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s) {
     const int nblocks = (NB + SB - 1) / SB;
     hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB);
     hipLaunchKernelGGL(k_scan_b, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr,
-                       gpart, n_gblocks);
+                       gpart, n_gblocks, host_hdr, host_seq);
 }
 
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,

@@ -224,7 +224,7 @@ struct GsrFwdParams {
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
-                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, hipStream_t s);
+                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s);
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
                         const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,

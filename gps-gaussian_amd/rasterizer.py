@@ -12,10 +12,12 @@ Host-side design notes (MI355X-first, not a translation of upstream's C++ glue):
   * one workspace tensor per forward replaces upstream's three resizable byte buffers and travels to backward in ctx;
   * upstream blocks on a D2H copy of `num_rendered` in the middle of every forward to size its sort buffers.  Here the
     whole forward is enqueued against an instance capacity learnt from previous calls; the kernels record the R they
-    needed + an overflow flag in the workspace header.  `GPSGS_CHECK=sync` (default) waits for that 64-byte header at
-    the END of the forward (no bubble inside the pipeline) and transparently re-runs with a larger capacity on
-    overflow, so results are always exact.  `GPSGS_CHECK=deferred` never blocks: the header lands in pinned memory
-    and is examined on the next call into this module; an overflow then raises (capacity grows for later calls).
+    needed + an overflow flag in the workspace header.  `GPSGS_CHECK=sync` (default) has the binning scan kernel store
+    that header straight into pinned host memory (gsr_forward_notify) and spins on it: the host learns R ~40 us into the
+    forward, while scatter / sort / compositing are still running, so the check costs no GPU idle time; on overflow it
+    transparently re-runs with a larger capacity, so results are always exact.  `GPSGS_CHECK=deferred` never blocks:
+    the header lands in pinned memory and is examined on the next call into this module; an overflow then raises
+    (capacity grows for later calls).
 """
 import ctypes as C
 import os
@@ -59,6 +61,7 @@ def set_stage_timing(on, stage=None):
 
 # ---- capacity policy --------------------------------------------------------------------------------------------
 _MIN_CAP = 1 << 16
+_early_notify = os.environ.get("GPSGS_EARLY_NOTIFY", "1") != "0"  # 0: sync mode waits for the whole forward (event after a header copy)
 _state = {}  # device index -> dict(ratio=instances per Gaussian seen so far, pending=[(event, pinned_header, P)])
 
 
@@ -119,7 +122,7 @@ def _ptr(t):
 
 
 class _HeaderRing:
-    """Pinned 16-byte header slots + reusable events (allocating pinned memory / events per call costs tens of us)."""
+    """Pinned 32-byte header slots + reusable events (allocating pinned memory / events per call costs tens of us)."""
 
     def __init__(self, n=64):
         self.buf = torch.zeros((n, 4), dtype=torch.int64).pin_memory()  # 32-byte header prefix per slot
@@ -128,10 +131,32 @@ class _HeaderRing:
         self.events = [torch.cuda.Event() for _ in range(n)]
         self.n, self.i = n, 0
 
+        self.np32 = self.np.view("uint32")  # [n, 8]; word 7 of a slot is the early-notification sequence number
+        self.seq = 0
+
     def next(self):
         i = self.i
         self.i = (i + 1) % self.n
         return self.np[i], C.c_void_p(self.base + 32 * i), self.events[i]
+
+    def next_notify(self):
+        """-> (int64[4] header view, uint32[8] view, pointer, sequence number the device will store in word 7)."""
+        i = self.i
+        self.i = (i + 1) % self.n
+        self.seq = self.seq % 0x7fffffff + 1  # never 0, never equal to what the slot holds from its previous use
+        return self.np[i], self.np32[i], C.c_void_p(self.base + 32 * i), self.seq
+
+
+def _wait_notify(w32, seq, cur_stream):
+    """Spin until the device has stored `seq` (gsr_forward_notify): typically the preprocess + scan time, ~40 us."""
+    n = 0
+    while int(w32[7]) != seq:
+        n += 1
+        if n & 0x3ff == 0 and cur_stream.query():  # the stream drained without the store: surface the device error
+            if int(w32[7]) == seq:
+                break
+            torch.cuda.synchronize()
+            raise RuntimeError("gps_gaussian_amd: the rasteriser forward finished without publishing its header")
 
 
 _rings = {}
@@ -225,6 +250,22 @@ class _RasterizeGaussians(torch.autograd.Function):
             while True:
                 nbytes = ws_bytes(P, W, H, cap)
                 ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+                if mode == "sync" and P > 0 and _early_notify:
+                    # the device publishes the instance count to pinned memory right after the binning scan; the host
+                    # checks capacity while scatter / sort / compositing are still running (no GPU idle time)
+                    hdr, w32, hdr_ptr, seq = ring.next_notify()
+                    rc = lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
+                                                float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
+                                                _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
+                                                stream, hdr_ptr, seq)
+                    _capi.check(rc, "gsr_forward_notify")
+                    _wait_notify(w32, seq, cur_stream)
+                    R, overflow, need = _decode(hdr)
+                    _learn(st, R, need, P)
+                    if not overflow:
+                        break
+                    cap = _capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
+                    continue
                 rc = lib.gsr_forward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),
                                      _ptr(radii), _ptr(ws), nbytes, cap, flags, stream)

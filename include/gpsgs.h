@@ -86,6 +86,20 @@ int gsr_forward(int P, int width, int height, const float *means3D, const float 
                 const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
                 void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream);
 
+/* gsr_forward with EARLY capacity notification.  `host_header_out` is 32 bytes of PINNED host memory the device can write
+ * (hipHostMalloc / hipHostRegister; torch pin_memory()).  As soon as the binning scan knows the instance count -- about a fifth
+ * of the way into the forward, before scatter / sort / compositing run -- the device stores the first 28 header bytes
+ * {u64 num_rendered; u32 overflow, max_tile_count, num_busy_wgs, num_slots, 0} there and then release-stores `notify_seq`
+ * (non-zero, chosen by the caller, different from the word's current value) into the u32 at byte 28.  The host spins on that
+ * word instead of waiting for the whole forward: the capacity check of the reference's blocking `num_rendered` readback
+ * (rasterizer_impl.cu forward, cudaMemcpy of the scan total) then costs no GPU idle time.  With P == 0 nothing is written.
+ * GPSGS_E_INVALID if the pointer is not device-visible pinned memory or notify_seq == 0. */
+int gsr_forward_notify(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                       const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                       const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                       void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream,
+                       void *host_header_out, uint32_t notify_seq);
+
 /* Backward.  Same inputs and the workspace left by the matching gsr_forward, plus dL_dpix[3,H,W] (contiguous).
  * Writes (does not accumulate) dL_dmeans3D[P,3], dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P],
  * dL_dscales[P,3], dL_drotations[P,4]. */

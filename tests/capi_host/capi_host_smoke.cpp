@@ -76,6 +76,31 @@ int main() {
     // d(sum of pixels)/d colour = sum over pixels of alpha*T >= 0, and > 0 for every Gaussian that was drawn
     double gsum = 0; for (float v : hgc) { if (!(v >= 0.f) || !std::isfinite(v)) { printf("bad colour gradient %f\n", v); return 1; } gsum += v; }
     if (!(gsum > 0)) { printf("zero gradient\n"); return 1; }
+    // early notification: the scan kernel stores the header into pinned host memory; the host spins on the sequence word
+    {
+        volatile uint32_t *pin = nullptr;
+        CK(hipHostMalloc((void **)&pin, 32, hipHostMallocDefault));
+        for (int k = 0; k < 8; k++) pin[k] = 0;
+        rc = gsr_forward_notify(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color, radii, ws, nbytes, cap, 0, st,
+                                (void *)pin, 77u);
+        if (rc != GPSGS_OK) { printf("gsr_forward_notify rc=%d\n", rc); return 1; }
+        long spins = 0;
+        while (pin[7] != 77u) {
+            if (++spins > 2000000000L) { printf("notification never arrived\n"); return 1; }
+        }
+        const uint64_t Rn = (uint64_t)pin[0] | ((uint64_t)pin[1] << 32);
+        if (Rn != h.num_rendered || pin[2] != 0u || pin[3] != h.max_tile_count || pin[4] != h.num_busy_wgs || pin[5] != h.num_slots) {
+            printf("notified header differs: R=%llu ovf=%u max=%u busy=%u slots=%u\n", (unsigned long long)Rn, pin[2], pin[3], pin[4], pin[5]);
+            return 1;
+        }
+        CK(hipStreamSynchronize(st));
+        int not_pinned[8];
+        if (gsr_forward_notify(P, W, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, nbytes, cap, 0, st, not_pinned, 5u) !=
+            GPSGS_E_INVALID) { printf("pageable notify target was accepted\n"); return 1; }
+        if (gsr_forward_notify(P, W, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, nbytes, cap, 0, st, (void *)pin, 0u) !=
+            GPSGS_E_INVALID) { printf("notify_seq 0 was accepted\n"); return 1; }
+        CK(hipHostFree((void *)pin));
+    }
     // argument checking happens before any launch
     if (gsr_forward(P, 0, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, nbytes, cap, 0, st) != GPSGS_E_INVALID) return 1;
     if (gsr_forward(P, W, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, 64, cap, 0, st) != GPSGS_E_WORKSPACE) return 1;

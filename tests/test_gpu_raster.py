@@ -200,9 +200,13 @@ def test_every_sort_path(n, expect_path):
         assert np.quantile(e[~touched], 0.999) <= GRAD_TOL if (~touched).any() else True, k
 
 
-def test_capacity_overflow_is_detected_and_repaired(monkeypatch):
+@pytest.mark.parametrize("early", [True, False], ids=["early-notify", "header-copy"])
+def test_capacity_overflow_is_detected_and_repaired(monkeypatch, early):
+    """Both sync-mode checks: the scan kernel's direct store to pinned memory (gsr_forward_notify, default) and the
+    end-of-forward header copy + event (GPSGS_EARLY_NOTIFY=0)."""
     from gps_gaussian_amd import rasterizer as RZ
     from gps_gaussian_amd import synthetic as S
+    monkeypatch.setattr(RZ, "_early_notify", early)
     g = S.make_uniform_cloud(5000, 128, 96, seed=9, scale_med=0.05)
     o, oimg, _ = oracle_render(g, "f32")
     assert o.num_rendered > 4 * 1024
