@@ -215,7 +215,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
     const int64_t max_last = (int64_t)__builtin_amdgcn_readfirstlane((int)m);
     if (max_last == 0) return;
 
-    float T = T_final, ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    float T = T_final, A = 0.f;  // A = (colour accumulated behind the current splat) . dL/dpixel
+    const float nTb = -T_final * bg_dot;
 
     // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
@@ -257,30 +258,31 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
             // Per pair only the colour terms and six MOMENTS of s = dL/dG * G are formed: S0 = sum s, Sx = sum s dx, Sy, Sxx,
             // Sxy, Syy.  dL/dmean2D, dL/dconic and dL/dopacity are linear in them and are finished once per (bin, splat)
             // at flush time (11 fewer instructions per pair than forming the nine upstream terms here).
-            float g_r = 0.f, g_g = 0.f, g_b = 0.f, m_x = 0.f, m_y = 0.f, m_xx = 0.f, m_xy = 0.f, m_yy = 0.f, m_0 = 0.f;
-            if (valid) {
-                const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = T * rcp;
-                const float dchannel_dcolor = alpha * T;
-                const float c0 = b.z, c1 = b.w, c2 = wC[j];
-                ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
-                ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
-                ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
-                lc0 = c0; lc1 = c1; lc2 = c2;
-                float dL_dalpha = (c0 - ar0) * d0 + (c1 - ar1) * d1 + (c2 - ar2) * d2;
-                g_r = dchannel_dcolor * d0;
-                g_g = dchannel_dcolor * d1;
-                g_b = dchannel_dcolor * d2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final * rcp) * bg_dot;
-                m_0 = (b.y * dL_dalpha) * G;  // s = dL/dG * G, with dL/dG = opacity * dL/dalpha straight through the 0.99 clamp
-                m_x = m_0 * dx;
-                m_y = m_0 * dy;
-                m_xx = m_x * dx;
-                m_xy = m_x * dy;
-                m_yy = m_y * dy;
-            }
+            // Branch-free: a lane this splat does not reach (behind its last contributor, power > 0, alpha < 1/255) runs the
+            // same arithmetic with alpha = 0 and G = 0: rcp(1) = 1 leaves T, the recurrence below leaves A (0 * cd + 1 * A), and
+            // every sum receives an exact zero.
+            // Upstream carries accum_rec (the colour seen behind the splat, 3 channels) with last_alpha / last_color; only its
+            // dot product with dL/dpixel is ever used, so the recurrence is carried on that scalar: A <- alpha cd + (1 - alpha) A
+            // with cd = colour . dL/dpixel.  Same order of operations back to front (no cancellation), 14 instead of 23
+            // instructions, and nothing but T and A is carried from splat to splat.
+            const float Ge = valid ? G : 0.f;
+            const float ae = valid ? alpha : 0.f;
+            const float om = 1.f - ae;
+            const float rcp = __builtin_amdgcn_rcpf(om);
+            T = T * rcp;
+            const float cd = b.z * d0 + b.w * d1 + wC[j] * d2;
+            const float w = ae * T;  // dchannel/dcolour
+            const float dL_dalpha = (cd - A) * T + nTb * rcp;
+            A = ae * cd + om * A;
+            const float g_r = w * d0;
+            const float g_g = w * d1;
+            const float g_b = w * d2;
+            const float m_0 = (b.y * dL_dalpha) * Ge;  // s = dL/dG * G, with dL/dG = opacity * dL/dalpha straight through the 0.99 clamp
+            const float m_x = m_0 * dx;
+            const float m_y = m_0 * dy;
+            const float m_xx = m_x * dx;
+            const float m_xy = m_x * dy;
+            const float m_yy = m_y * dy;
             const float red[9] = {g_r, g_g, g_b, m_x, m_y, m_xx, m_xy, m_yy, m_0};
             const float out = wave_reduce_scatter9(red, (lane & 8) != 0);
             if (slot >= 0) wAccF[12 * j + slot] = out;  // 12 lanes, 12 distinct words of this splat's record
