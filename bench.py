@@ -202,7 +202,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d (Gaussian, 8x8-bin) instances, "
                                    "HIP rasteriser forward+backward, one view per step per GPU" % (W, H, P, R),
-                       "check_mode": "sync (exact; 64-byte header read back at the end of every forward)"},
+                       "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "forward_only_views_per_s": round(world * args.steps / el_fwd, 2),
             "deferred_check_views_per_s": {"fwd_bwd": round(world * args.steps / el_def, 2), "fwd": round(world * args.steps / el_fwd_def, 2)},

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ b
     else sort_wave_regs<16>(seg, n, out, lane);
 }
 
-// lists longer than 1024 keys are rare: a small persistent grid of 1024-thread workgroups (128 KiB LDS each) strides
+// lists longer than 1024 keys are rare: a small persistent grid (64) of 1024-thread workgroups (128 KiB LDS each) strides
 // over the bins and picks them up (launching one big workgroup per bin just to exit cost ~18 us at 16,384 bins)
 __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
                                                      uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
@@ -347,5 +347,5 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
                      const GsrHeader *hdr, hipStream_t s) {
     if (NB <= 0) return;
     hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
-    hipLaunchKernelGGL(k_sort_large, dim3(NB < 256 ? NB : 256), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_large, dim3(NB < 64 ? NB : 64), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

@@ -290,10 +290,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.cap = cap
         ctx.save_for_backward(m3, col, opa, sca, rot, view, proj, bg, radii, ws)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # otherwise autograd fills a zero int32 [P] "gradient" for radii on every backward
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
+        if grad_out_color is None:  # the image did not take part in the loss
+            return (None,) * 9
         rs = ctx.raster_settings
         lib = _capi.lib()
         m3, col, opa, sca, rot, view, proj, bg, radii, ws = ctx.saved_tensors
