@@ -10,6 +10,7 @@ SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
+    "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward",
 )
 
 GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
@@ -87,6 +88,18 @@ def lib():
     l.cs_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     l.cs_backward.restype = i32
     l.cs_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    l.cv_build_forward.restype = i32
+    l.cv_build_forward.argtypes = [vp, vp, pp, i32, i32, i32, i32, i32, i32, i32, vp]
+    l.cv_build_backward.restype = i32
+    l.cv_build_backward.argtypes = [vp, vp, pp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    l.cs_lookup_forward.restype = i32
+    l.cs_lookup_forward.argtypes = [pp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    l.cs_lookup_backward.restype = i32
+    l.cs_lookup_backward.argtypes = [vp, vp, pp, i32, i32, i32, i32, i32, i32, i32, vp]
+    l.cu_upsample_forward.restype = i32
+    l.cu_upsample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    l.cu_upsample_backward.restype = i32
+    l.cu_upsample_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     if l.gpsgs_abi_version() != 1:
         raise ImportError("gps_gaussian_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = l

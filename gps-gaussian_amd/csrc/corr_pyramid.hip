@@ -1,0 +1,471 @@
+// corr_pyramid.hip -- the neighbours of the 1-D correlation sampler inside RAFT-Stereo, for gfx950:
+//
+//   cv_build_forward / cv_build_backward     all-pairs 1-D correlation volume + its average-pool pyramid
+//                                            (/root/reference/core/corr.py:31-61: CorrBlockFast1D.__init__ / .corr)
+//   cs_lookup_forward / cs_lookup_backward   the 2r+1-tap lookup in ALL pyramid levels in one launch, written straight into the
+//                                            concatenated [N, L*(2r+1), H, W] tensor (core/corr.py:44-51: CorrBlockFast1D.__call__)
+//   cu_upsample_forward / cu_upsample_backward   convex-combination upsampling of the flow (core/raft_stereo_human.py:69-81)
+//
+// The volume is GEMM-shaped work -- per (image, row): C[w1, w2] = sum_d F1[d, w1] F2[d, w2] / sqrt(D), 128 x 192 x 128 at the
+// reference's sizes, 2B * 128 of them -- so it runs on the matrix cores: fp32 MFMA (v_mfma_f32_32x32x2_f32), one 32 x 32
+// accumulator tile per wave64, operands staged through LDS in K-major order so every MFMA operand fetch is a conflict-free
+// 128-byte row.  The epilogue applies 1/sqrt(D) and produces the whole pyramid from the accumulators (neighbouring w2
+// columns live in neighbouring lanes: three lane-xor exchanges), so the level-0 volume is never re-read.  The backward
+// folds the four per-level gradients back into d(level 0) while it stages that operand, and runs the two transposed GEMMs
+// with the same tile engine.  fp16 tensors (stage 2 runs under AMP) are widened on load and rounded once on store.
+#include <hip/hip_fp16.h>
+
+#include "gsr_common.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <typename T> __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ldf<__half>(const __half *p) { return __half2float(*p); }
+template <typename T> __device__ __forceinline__ void stf(T *p, float v);
+template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<__half>(__half *p, float v) { *p = __float2half(v); }
+template <typename T> __device__ __forceinline__ float rnd(float v);  // round to the storage type (fp16 pyramids are pooled level by level)
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<__half>(float v) { return __half2float(__float2half(v)); }
+
+constexpr int TM = 64, TN = 64, TK = 32;  // workgroup tile; 4 waves, each one 32 x 32 MFMA accumulator
+constexpr int LDS_LD = TM + 1;            // +1 float: the transposing stores of k-contiguous operands stay conflict-free
+
+// ---- tile engine ------------------------------------------------------------------------------------------------------
+// C[m, n] = sum_k A(m, k) B(k, n) for one (m0, n0) workgroup tile.  fetchA(m, k) / fetchB(k, n) return the operand element (0
+// outside the problem); a_k_contig / b_k_contig say which index is contiguous in memory so the staging loads coalesce.
+// On return acc holds the wave's 32 x 32 tile: register v of lane l is row (v / 4) * 8 + (l / 32) * 4 + v % 4, column l % 32.
+template <bool A_K_CONTIG, bool B_K_CONTIG, typename FA, typename FB>
+__device__ __forceinline__ void tile_gemm(int K, FA fetchA, FB fetchB, float (*As)[LDS_LD], float (*Bs)[LDS_LD], v16f &acc) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = (wid & 1) * 32, wn = (wid >> 1) * 32;
+#pragma unroll
+    for (int v = 0; v < 16; v++) acc[v] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += TK) {
+        __syncthreads();
+#pragma unroll
+        for (int e = tid; e < TK * TM; e += 256) {
+            int kk, mm;
+            if (A_K_CONTIG) { kk = e % TK; mm = e / TK; } else { mm = e % TM; kk = e / TM; }
+            As[kk][mm] = fetchA(mm, k0 + kk);
+        }
+#pragma unroll
+        for (int e = tid; e < TK * TN; e += 256) {
+            int kk, nn;
+            if (B_K_CONTIG) { kk = e % TK; nn = e / TK; } else { nn = e % TN; kk = e / TN; }
+            Bs[kk][nn] = fetchB(k0 + kk, nn);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+}
+
+// ---- forward: volume + pyramid ----------------------------------------------------------------------------------------
+struct PyrPtrs {
+    void *p[4];
+};
+struct PyrConstPtrs {
+    const void *p[4];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cv_fwd(const T *__restrict__ f1, const T *__restrict__ f2, PyrPtrs pyr, int D, int H, int W1, int W2,
+                                                int levels, float scale) {
+    __shared__ float As[TK][LDS_LD];
+    __shared__ float Bs[TK][LDS_LD];
+    const int g = blockIdx.z;  // n * H + h
+    const int n = g / H, h = g - n * H;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const T *a = f1 + ((size_t)n * D * H + h) * W1;  // element (d, w1) at a[d * H * W1 + w1]
+    const T *b = f2 + ((size_t)n * D * H + h) * W2;
+    const size_t lda = (size_t)H * W1, ldb = (size_t)H * W2;
+    v16f acc;
+    tile_gemm<false, false>(
+        D, [&](int mm, int k) { return (m0 + mm < W1 && k < D) ? ldf(a + (size_t)k * lda + m0 + mm) : 0.f; },
+        [&](int k, int nn) { return (n0 + nn < W2 && k < D) ? ldf(b + (size_t)k * ldb + n0 + nn) : 0.f; }, As, Bs, acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = n0 + (wid >> 1) * 32 + (lane & 31);  // w2
+    const int row0 = m0 + (wid & 1) * 32 + (lane >> 5) * 4;
+    // widths of the pyramid levels: avg_pool2d([1, 2], stride [1, 2]) floors
+    int wl[4];
+    wl[0] = W2;
+#pragma unroll
+    for (int l = 1; l < 4; l++) wl[l] = wl[l - 1] >> 1;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int w1 = row0 + (v >> 2) * 8 + (v & 3);
+        float c = rnd<T>(acc[v] * scale);
+        const bool row_ok = w1 < W1;
+        const size_t rowbase = (size_t)g * W1 + w1;
+        if (row_ok && col < W2) stf(reinterpret_cast<T *>(pyr.p[0]) + rowbase * wl[0] + col, c);
+        // level l+1 = 0.5 (even + odd neighbour) of level l: the neighbour sits 2^l lanes away
+#pragma unroll
+        for (int l = 1; l < 4; l++) {
+            const float o = __shfl_xor(c, 1 << (l - 1), 64);
+            c = rnd<T>(0.5f * (c + o));
+            if (l < levels) {
+                const int cl = col >> l;
+                if (row_ok && (col & ((1 << l) - 1)) == 0 && cl < wl[l]) stf(reinterpret_cast<T *>(pyr.p[l]) + rowbase * wl[l] + cl, c);
+            }
+        }
+    }
+}
+
+// ---- backward: d(level 0) folded from the per-level gradients, then the two transposed GEMMs ------------------------------
+// d(level 0)[w1, w2] = g0 + g1[w2 / 2] / 2 + g2[w2 / 4] / 4 + g3[w2 / 8] / 8, each term only where the pooling window is complete
+template <typename T>
+__device__ __forceinline__ float fold_grad(const PyrConstPtrs &gp, int levels, size_t rowbase, int w2, int W2) {
+    float s = 0.f, wgt = 1.f;
+    int wl = W2, c = w2;
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        if (l < levels && gp.p[l] && c < wl) s += wgt * ldf(reinterpret_cast<const T *>(gp.p[l]) + rowbase * wl + c);
+        wl >>= 1;
+        c >>= 1;
+        wgt *= 0.5f;
+    }
+    return s;
+}
+
+// grad_f1[d, w1] = scale * sum_w2 F2[d, w2] dC[w1, w2]      (M = d, N = w1, K = w2; both operands contiguous in k)
+// grad_f2[d, w2] = scale * sum_w1 F1[d, w1] dC[w1, w2]      (M = d, N = w2, K = w1; A contiguous in k, B contiguous in n)
+template <typename T, bool WRT_F1>
+__global__ __launch_bounds__(256) void k_cv_bwd(const T *__restrict__ fother, PyrConstPtrs gp, T *__restrict__ gout, int D, int H, int W1, int W2,
+                                                int levels, float scale) {
+    __shared__ float As[TK][LDS_LD];
+    __shared__ float Bs[TK][LDS_LD];
+    const int g = blockIdx.z;
+    const int n = g / H, h = g - n * H;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;  // m = d, n = w1 (WRT_F1) or w2
+    const int Wk = WRT_F1 ? W2 : W1, Wn = WRT_F1 ? W1 : W2;
+    const T *fo = fother + ((size_t)n * D * H + h) * Wk;  // (d, k) at fo[d * H * Wk + k]
+    const size_t ldf_ = (size_t)H * Wk;
+    v16f acc;
+    auto fa = [&](int mm, int k) { return (m0 + mm < D && k < Wk) ? ldf(fo + (size_t)(m0 + mm) * ldf_ + k) : 0.f; };
+    if (WRT_F1) {
+        tile_gemm<true, true>(
+            Wk, fa, [&](int k, int nn) { return (n0 + nn < W1 && k < W2) ? fold_grad<T>(gp, levels, (size_t)g * W1 + n0 + nn, k, W2) : 0.f; }, As, Bs,
+            acc);
+    } else {
+        tile_gemm<true, false>(
+            Wk, fa, [&](int k, int nn) { return (n0 + nn < W2 && k < W1) ? fold_grad<T>(gp, levels, (size_t)g * W1 + k, n0 + nn, W2) : 0.f; }, As, Bs,
+            acc);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = n0 + (wid >> 1) * 32 + (lane & 31);
+    const int row0 = m0 + (wid & 1) * 32 + (lane >> 5) * 4;
+    T *o = gout + ((size_t)n * D * H + h) * Wn;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int d = row0 + (v >> 2) * 8 + (v & 3);
+        if (d < D && col < Wn) stf(o + (size_t)d * H * Wn + col, acc[v] * scale);
+    }
+}
+
+// ---- fused multi-level lookup -------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+template <typename T>
+__global__ __launch_bounds__(256) void k_lookup_fwd(PyrConstPtrs pyr, const float *__restrict__ coords, T *__restrict__ out, int total, int H1,
+                                                    int W1, int W2, int levels, int r) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // (n*H1 + y)*W1 + x
+    if (idx >= total) return;
+    const int hw = H1 * W1;
+    const int n = idx / hw, yx = idx - n * hw;
+    const int rd = 2 * r + 1;
+    const float x = coords[idx];
+    int wl = W2;
+    float inv = 1.f;
+    for (int l = 0; l < levels; l++) {
+        const float x0 = x * inv;  // coords / 2^l is exact
+        const float fl = floorf(x0);
+        const float dx = x0 - fl;
+        const int xs = (int)fl - r;
+        const T *v = reinterpret_cast<const T *>(pyr.p[l]) + (size_t)idx * wl;
+        float prev = (xs >= 0 && xs < wl) ? ldf(v + xs) : 0.f;
+        T *o = out + ((size_t)n * levels * rd + (size_t)l * rd) * hw + yx;
+        for (int k = 0; k < rd; k++) {
+            const int x1 = xs + k + 1;
+            const float next = (x1 >= 0 && x1 < wl) ? ldf(v + x1) : 0.f;
+            stf(o + (size_t)k * hw, prev * (1.0f - dx) + next * dx);
+            prev = next;
+        }
+        wl >>= 1;
+        inv *= 0.5f;
+    }
+}
+
+// one thread per level-0 COLUMN position e = (row idx, c): writes element c of every level whose row is at least c+1 wide
+// (each gradient row is owned by one (n, y, x), so there is no scatter and the zero fill is fused)
+template <typename T>
+__global__ __launch_bounds__(256) void k_lookup_bwd(const float *__restrict__ coords, const T *__restrict__ grad_out, PyrPtrs gpyr, size_t total,
+                                                    int H1, int W1, int W2, int levels, int r) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % W2);
+    const size_t idx = e / W2;
+    const int hw = H1 * W1;
+    const int n = (int)(idx / hw), yx = (int)(idx - (size_t)n * hw);
+    const int rd = 2 * r + 1;
+    const float x = coords[idx];
+    int wl = W2;
+    float inv = 1.f;
+    for (int l = 0; l < levels; l++) {
+        if (c < wl) {
+            const float x0 = x * inv;
+            const float fl = floorf(x0);
+            const float dx = x0 - fl;
+            const int i = c - ((int)fl - r);  // tap index of this element, valid 0..rd
+            float gsum = 0.f;
+            if (i >= 0 && i <= rd) {
+                const T *go = grad_out + ((size_t)n * levels * rd + (size_t)l * rd) * hw + yx;
+                if (i > 0) gsum += ldf(go + (size_t)(i - 1) * hw) * dx;
+                if (i < rd) gsum += ldf(go + (size_t)i * hw) * (1.0f - dx);
+            }
+            stf(reinterpret_cast<T *>(gpyr.p[l]) + idx * wl + c, gsum);
+        }
+        wl >>= 1;
+        inv *= 0.5f;
+    }
+}
+
+// ---- convex upsampling --------------------------------------------------------------------------------------------------
+// out[n, c, h f + i, w f + j] = sum_k softmax_k(mask[n, k f^2 + i f + j, h, w]) * f * flow[n, c, h + k / 3 - 1, w + k % 3 - 1]   (zero padded)
+// One thread per (n, h, w, i, j) with the fine column fastest: mask reads walk j (stride H W: the 9 f^2 planes are read
+// once, coalesced along w for fixed (i, j) by the neighbouring threads of other w), output stores are coalesced.
+__global__ __launch_bounds__(256) void k_up_fwd(const float *__restrict__ flow, const float *__restrict__ mask, float *__restrict__ out, int N, int C,
+                                                int H, int W, int f) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((n * H f + y) * W f + x)
+    const int WF = W * f, HF = H * f;
+    const size_t total = (size_t)N * HF * WF;
+    if (t >= total) return;
+    const int x = (int)(t % WF), y = (int)((t / WF) % HF), n = (int)(t / ((size_t)WF * HF));
+    const int w = x / f, j = x - w * f, h = y / f, i = y - h * f;
+    const size_t hw = (size_t)H * W;
+    const float *m = mask + ((size_t)n * 9 * f * f + (size_t)i * f + j) * hw + (size_t)h * W + w;
+    float lg[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        lg[k] = m[(size_t)k * f * f * hw];
+        mx = fmaxf(mx, lg[k]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        lg[k] = expf(lg[k] - mx);
+        den += lg[k];
+    }
+    const float inv = 1.f / den;
+    for (int c = 0; c < C; c++) {
+        const float *fl = flow + ((size_t)n * C + c) * hw;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int hh = h + k / 3 - 1, ww = w + k % 3 - 1;
+            const float v = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? (float)f * fl[(size_t)hh * W + ww] : 0.f;
+            s += (lg[k] * inv) * v;
+        }
+        out[(((size_t)n * C + c) * HF + y) * WF + x] = s;
+    }
+}
+
+// grad_mask: per fine pixel p = softmax, u_k = sum_c g[c] f flow_c[k]; dlogit_k = p_k (u_k - sum_j p_j u_j)
+__global__ __launch_bounds__(256) void k_up_bwd_mask(const float *__restrict__ flow, const float *__restrict__ mask, const float *__restrict__ gout,
+                                                     float *__restrict__ gmask, int N, int C, int H, int W, int f) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int WF = W * f, HF = H * f;
+    const size_t total = (size_t)N * HF * WF;
+    if (t >= total) return;
+    const int x = (int)(t % WF), y = (int)((t / WF) % HF), n = (int)(t / ((size_t)WF * HF));
+    const int w = x / f, j = x - w * f, h = y / f, i = y - h * f;
+    const size_t hw = (size_t)H * W;
+    const size_t moff = ((size_t)n * 9 * f * f + (size_t)i * f + j) * hw + (size_t)h * W + w;
+    float p[9], u[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        p[k] = mask[moff + (size_t)k * f * f * hw];
+        mx = fmaxf(mx, p[k]);
+        u[k] = 0.f;
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        p[k] = expf(p[k] - mx);
+        den += p[k];
+    }
+    const float inv = 1.f / den;
+    for (int c = 0; c < C; c++) {
+        const float gc = gout[(((size_t)n * C + c) * HF + y) * WF + x];
+        const float *fl = flow + ((size_t)n * C + c) * hw;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int hh = h + k / 3 - 1, ww = w + k % 3 - 1;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) u[k] += gc * ((float)f * fl[(size_t)hh * W + ww]);
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        p[k] *= inv;
+        dot += p[k] * u[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) gmask[moff + (size_t)k * f * f * hw] = p[k] * (u[k] - dot);
+}
+
+// grad_flow[n, c, hh, ww] = f * sum over the 9 coarse cells (h, w) = (hh - dy, ww - dx) and their f^2 fine pixels of p_k g
+// (a gather: one thread per coarse flow element, fixed summation order, no atomics)
+__global__ __launch_bounds__(256) void k_up_bwd_flow(const float *__restrict__ mask, const float *__restrict__ gout, float *__restrict__ gflow, int N,
+                                                     int C, int H, int W, int f) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // (n * H + hh) * W + ww
+    const size_t total = (size_t)N * H * W;
+    if (t >= total) return;
+    const int ww = (int)(t % W), hh = (int)((t / W) % H), n = (int)(t / ((size_t)W * H));
+    const int WF = W * f, HF = H * f;
+    const size_t hw = (size_t)H * W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // C <= 4
+    for (int k = 0; k < 9; k++) {
+        const int h = hh - (k / 3 - 1), w = ww - (k % 3 - 1);
+        if (h < 0 || h >= H || w < 0 || w >= W) continue;
+        for (int i = 0; i < f; i++)
+            for (int j = 0; j < f; j++) {
+                const size_t moff = ((size_t)n * 9 * f * f + (size_t)i * f + j) * hw + (size_t)h * W + w;
+                float mx = -INFINITY, den = 0.f, pk = 0.f;
+#pragma unroll
+                for (int q = 0; q < 9; q++) mx = fmaxf(mx, mask[moff + (size_t)q * f * f * hw]);
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const float e = expf(mask[moff + (size_t)q * f * f * hw] - mx);
+                    den += e;
+                    if (q == k) pk = e;
+                }
+                pk /= den;
+                for (int c = 0; c < C; c++) acc[c] += pk * gout[(((size_t)n * C + c) * HF + (size_t)h * f + i) * WF + (size_t)w * f + j];
+            }
+    }
+    for (int c = 0; c < C; c++) gflow[((size_t)n * C + c) * hw + (size_t)hh * W + ww] = (float)f * acc[c];
+}
+
+}  // namespace
+
+static bool dims_ok(int N, int D, int H, int W1, int W2, int levels, int dtype) {
+    return N >= 0 && D >= 0 && H >= 0 && W1 >= 0 && W2 >= 0 && levels >= 1 && levels <= 4 && (dtype == 0 || dtype == 1);
+}
+
+extern "C" int cv_build_forward(const void *fmap1, const void *fmap2, void *const *pyramid, int N, int D, int H, int W1, int W2, int levels, int dtype,
+                                void *stream) {
+    if (!dims_ok(N, D, H, W1, W2, levels, dtype) || !pyramid) return GPSGS_E_INVALID;
+    if ((size_t)N * H == 0 || W1 == 0 || W2 == 0) return GPSGS_OK;
+    if (!fmap1 || !fmap2 || (size_t)N * H > 65535u) return GPSGS_E_INVALID;
+    PyrPtrs pp;
+    for (int l = 0; l < 4; l++) {
+        pp.p[l] = l < levels ? pyramid[l] : nullptr;
+        if (l < levels && !pp.p[l] && (W2 >> l) > 0) return GPSGS_E_INVALID;
+    }
+    const dim3 grid((W2 + TN - 1) / TN, (W1 + TM - 1) / TM, N * H);
+    const float scale = 1.0f / sqrtf((float)D);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_cv_fwd<float>, grid, dim3(256), 0, s, (const float *)fmap1, (const float *)fmap2, pp, D, H, W1, W2, levels, scale);
+    else
+        hipLaunchKernelGGL(k_cv_fwd<__half>, grid, dim3(256), 0, s, (const __half *)fmap1, (const __half *)fmap2, pp, D, H, W1, W2, levels, scale);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
+extern "C" int cv_build_backward(const void *fmap1, const void *fmap2, const void *const *grad_pyramid, void *grad_fmap1, void *grad_fmap2, int N, int D,
+                                 int H, int W1, int W2, int levels, int dtype, void *stream) {
+    if (!dims_ok(N, D, H, W1, W2, levels, dtype) || !grad_pyramid) return GPSGS_E_INVALID;
+    if ((size_t)N * H == 0 || D == 0) return GPSGS_OK;
+    if (!fmap1 || !fmap2 || (!grad_fmap1 && !grad_fmap2) || (size_t)N * H > 65535u) return GPSGS_E_INVALID;
+    PyrConstPtrs gp;
+    for (int l = 0; l < 4; l++) gp.p[l] = l < levels ? grad_pyramid[l] : nullptr;
+    const float scale = 1.0f / sqrtf((float)D);
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_fmap1 && W1 > 0) {
+        const dim3 grid((W1 + TN - 1) / TN, (D + TM - 1) / TM, N * H);
+        if (dtype == 0)
+            hipLaunchKernelGGL((k_cv_bwd<float, true>), grid, dim3(256), 0, s, (const float *)fmap2, gp, (float *)grad_fmap1, D, H, W1, W2, levels, scale);
+        else
+            hipLaunchKernelGGL((k_cv_bwd<__half, true>), grid, dim3(256), 0, s, (const __half *)fmap2, gp, (__half *)grad_fmap1, D, H, W1, W2, levels, scale);
+    }
+    if (grad_fmap2 && W2 > 0) {
+        const dim3 grid((W2 + TN - 1) / TN, (D + TM - 1) / TM, N * H);
+        if (dtype == 0)
+            hipLaunchKernelGGL((k_cv_bwd<float, false>), grid, dim3(256), 0, s, (const float *)fmap1, gp, (float *)grad_fmap2, D, H, W1, W2, levels, scale);
+        else
+            hipLaunchKernelGGL((k_cv_bwd<__half, false>), grid, dim3(256), 0, s, (const __half *)fmap1, gp, (__half *)grad_fmap2, D, H, W1, W2, levels, scale);
+    }
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
+extern "C" int cs_lookup_forward(const void *const *pyramid, const float *coords, void *out, int N, int H1, int W1, int W2, int levels, int radius,
+                                 int dtype, void *stream) {
+    if (!dims_ok(N, 0, H1, W1, W2, levels, dtype) || radius < 0 || !pyramid) return GPSGS_E_INVALID;
+    const long long total = (long long)N * H1 * W1;
+    if (total == 0) return GPSGS_OK;
+    if (!coords || !out || total > 0x7fffffffLL) return GPSGS_E_INVALID;
+    PyrConstPtrs pp;
+    for (int l = 0; l < 4; l++) {
+        pp.p[l] = l < levels ? pyramid[l] : nullptr;
+        if (l < levels && !pp.p[l] && (W2 >> l) > 0) return GPSGS_E_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_lookup_fwd<float>, grid, dim3(256), 0, s, pp, coords, (float *)out, (int)total, H1, W1, W2, levels, radius);
+    else
+        hipLaunchKernelGGL(k_lookup_fwd<__half>, grid, dim3(256), 0, s, pp, coords, (__half *)out, (int)total, H1, W1, W2, levels, radius);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
+extern "C" int cs_lookup_backward(const float *coords, const void *grad_out, void *const *grad_pyramid, int N, int H1, int W1, int W2, int levels,
+                                  int radius, int dtype, void *stream) {
+    if (!dims_ok(N, 0, H1, W1, W2, levels, dtype) || radius < 0 || !grad_pyramid) return GPSGS_E_INVALID;
+    const size_t total = (size_t)N * H1 * W1 * W2;
+    if (total == 0) return GPSGS_OK;
+    if (!coords || !grad_out) return GPSGS_E_INVALID;
+    PyrPtrs pp;
+    for (int l = 0; l < 4; l++) {
+        pp.p[l] = l < levels ? grad_pyramid[l] : nullptr;
+        if (l < levels && !pp.p[l] && (W2 >> l) > 0) return GPSGS_E_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_lookup_bwd<float>, grid, dim3(256), 0, s, coords, (const float *)grad_out, pp, total, H1, W1, W2, levels, radius);
+    else
+        hipLaunchKernelGGL(k_lookup_bwd<__half>, grid, dim3(256), 0, s, coords, (const __half *)grad_out, pp, total, H1, W1, W2, levels, radius);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
+extern "C" int cu_upsample_forward(const float *flow, const float *mask, float *out, int N, int C, int H, int W, int factor, void *stream) {
+    if (N < 0 || C < 1 || C > 4 || H < 0 || W < 0 || factor < 1 || factor > 16) return GPSGS_E_INVALID;
+    const size_t total = (size_t)N * H * factor * W * factor;
+    if (total == 0) return GPSGS_OK;
+    if (!flow || !mask || !out) return GPSGS_E_INVALID;
+    hipLaunchKernelGGL(k_up_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flow, mask, out, N, C, H, W, factor);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
+extern "C" int cu_upsample_backward(const float *flow, const float *mask, const float *grad_out, float *grad_flow, float *grad_mask, int N, int C, int H,
+                                    int W, int factor, void *stream) {
+    if (N < 0 || C < 1 || C > 4 || H < 0 || W < 0 || factor < 1 || factor > 16) return GPSGS_E_INVALID;
+    const size_t total = (size_t)N * H * factor * W * factor;
+    if (total == 0) return GPSGS_OK;
+    if (!flow || !mask || !grad_out || (!grad_flow && !grad_mask)) return GPSGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_mask)
+        hipLaunchKernelGGL(k_up_bwd_mask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, flow, mask, grad_out, grad_mask, N, C, H, W, factor);
+    if (grad_flow) {
+        const size_t tf = (size_t)N * H * W;
+        hipLaunchKernelGGL(k_up_bwd_flow, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, s, mask, grad_out, grad_flow, N, C, H, W, factor);
+    }
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}

@@ -16,6 +16,11 @@
  *   cs_forward / cs_backward
  *       `corr_sampler.forward` / `corr_sampler.backward` of the external RAFT-Stereo sampler extension, called at
  *       core/corr.py:22 and core/corr.py:28.
+ *   cv_build_forward / cv_build_backward, cs_lookup_forward / cs_lookup_backward
+ *       CorrBlockFast1D: the all-pairs correlation volume + average-pool pyramid (core/corr.py:31-42, :53-61) and the lookup of
+ *       all levels with the concatenation of core/corr.py:44-51 (four corr_sampler.forward calls + torch.cat in the reference).
+ *   cu_upsample_forward / cu_upsample_backward
+ *       RAFTStereoHuman.upsample_flow, core/raft_stereo_human.py:69-81 (softmax over the 9 taps + unfold + weighted sum).
  *   gsr_pack_views / gsr_pack_views_backward
  *       the per-sample flatten + boolean-mask gather + concat + rgb affine of lib/GaussianRender.py:15-34.
  *   up_unproject_forward / up_unproject_backward
@@ -183,6 +188,28 @@ int cs_forward(const void *volume, const float *coords, void *out, int N, int H1
                int dtype, void *stream);
 int cs_backward(const float *coords, const void *grad_out, void *grad_volume, int N, int H1, int W1, int W2,
                 int radius, int dtype, void *stream);
+
+/* ---- correlation volume + pyramid, fused multi-level lookup, convex upsampling ----------
+ * fmap1[N,D,H,W1], fmap2[N,D,H,W2] (contiguous NCHW, the reference's fmap12 / fmap21); pyramid[l] is [N,H,W1,W2>>l] for
+ * l < levels (1..4), a HOST array of device pointers.  level 0 = sum_d fmap1 fmap2 / sqrt(D); level l+1 = average of
+ * neighbouring pairs of level l along W2 (avg_pool2d([1,2], stride [1,2]): an odd last column is dropped).
+ * dtype 0 = fp32, 1 = fp16 (inputs, pyramid and gradients; accumulation is always fp32, one rounding on store). */
+int cv_build_forward(const void *fmap1, const void *fmap2, void *const *pyramid, int N, int D, int H, int W1, int W2, int levels,
+                     int dtype, void *stream);
+/* grad_pyramid[l] may be NULL (level received no gradient); grad_fmap1 / grad_fmap2 may be NULL (not needed); both are
+ * written, not accumulated. */
+int cv_build_backward(const void *fmap1, const void *fmap2, const void *const *grad_pyramid, void *grad_fmap1, void *grad_fmap2, int N,
+                      int D, int H, int W1, int W2, int levels, int dtype, void *stream);
+/* out[N, levels*(2r+1), H1, W1]: channel l*(2r+1)+k = tap k of level l sampled at coords / 2^l (cs_forward semantics per level). */
+int cs_lookup_forward(const void *const *pyramid, const float *coords, void *out, int N, int H1, int W1, int W2, int levels, int radius,
+                      int dtype, void *stream);
+/* writes (zero-fills + taps) every grad_pyramid[l][N,H1,W1,W2>>l] */
+int cs_lookup_backward(const float *coords, const void *grad_out, void *const *grad_pyramid, int N, int H1, int W1, int W2, int levels,
+                       int radius, int dtype, void *stream);
+/* flow[N,C,H,W] (C <= 4), mask[N,9*f*f,H,W] logits, out[N,C,f*H,f*W]; fp32. */
+int cu_upsample_forward(const float *flow, const float *mask, float *out, int N, int C, int H, int W, int factor, void *stream);
+int cu_upsample_backward(const float *flow, const float *mask, const float *grad_out, float *grad_flow, float *grad_mask, int N, int C,
+                         int H, int W, int factor, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,10 @@ Fixtures (all produced by the reference's own code, on CPU):
   depth2pc_golden.npz      lib/utils.py::depth2pc on a small random inverse-depth map
   corr_sampler_golden.npz  core/corr.py::CorrBlock1D lookups (4 levels, radius 4) + autograd gradient w.r.t. each volume
   pts2render_golden.npz    lib/GaussianRender.py::pts2render's compaction: the exact arguments it hands to render()
+  loss_golden.npz          lib/loss.py::l1_loss / ssim and their autograd gradients
+  unproject_golden.npz     lib/utils.py::flow2depth + depth2pc and the gradient w.r.t. the flow
+  corr_pyramid_golden.npz  core/corr.py::CorrBlockFast1D.__init__ (volume + average-pool pyramid) and its gradient w.r.t. both feature maps
+  upsample_golden.npz      core/raft_stereo_human.py::FlowUpdateModule.upsample_flow and its gradients (flow, mask)
 """
 import os
 import sys
@@ -151,3 +155,33 @@ np.savez_compressed(os.path.join(HERE, "unproject_golden.npz"), ref_intr=ref_int
                     xyz=xyz_u.detach().numpy(), valid=(depth_u != 0).view(Bu, -1).numpy(), g_depth=gd.numpy(), g_xyz=gx.numpy(),
                     g_flow=gflow.numpy())
 print("unproject golden written")
+
+# ---- correlation volume + pyramid, convex upsampling (row f4) -------------------------------------------------------
+from core.corr import CorrBlockFast1D  # noqa: E402  (its constructor is pure PyTorch; only __call__ needs the CUDA sampler)
+from core.raft_stereo_human import FlowUpdateModule  # noqa: E402
+
+torch.manual_seed(23)
+Nc, Dc, Hc, W1c, W2c = 2, 24, 3, 45, 52          # ragged: W1 != W2, odd widths further down the pyramid (52, 26, 13, 6)
+f1c = torch.randn(Nc, Dc, Hc, W1c, requires_grad=True)
+f2c = torch.randn(Nc, Dc, Hc, W2c, requires_grad=True)
+blkf = CorrBlockFast1D(f1c, f2c, num_levels=4, radius=4)
+pyr = [p.squeeze(3) for p in blkf.corr_pyramid]
+gp = [torch.randn_like(p) for p in pyr]
+gf1, gf2 = torch.autograd.grad(sum((p * g).sum() for p, g in zip(pyr, gp)), (f1c, f2c))
+cp = {"fmap1": f1c.detach().numpy(), "fmap2": f2c.detach().numpy(), "grad_fmap1": gf1.numpy(), "grad_fmap2": gf2.numpy()}
+for l in range(4):
+    cp["pyr%d" % l] = pyr[l].detach().numpy()
+    cp["grad_pyr%d" % l] = gp[l].numpy()
+np.savez_compressed(os.path.join(HERE, "corr_pyramid_golden.npz"), **cp)
+
+torch.manual_seed(29)
+Nu, Hu, Wu, fu = 2, 5, 7, 4
+flow_c = torch.randn(Nu, 2, Hu, Wu, requires_grad=True)
+mask_c = (2.0 * torch.randn(Nu, 9 * fu * fu, Hu, Wu)).requires_grad_(True)
+fake_self = SimpleNamespace(args=SimpleNamespace(n_downsample=2))
+up = FlowUpdateModule.upsample_flow(fake_self, flow_c, mask_c)
+gup = torch.randn_like(up)
+gfl, gmk = torch.autograd.grad((up * gup).sum(), (flow_c, mask_c))
+np.savez_compressed(os.path.join(HERE, "upsample_golden.npz"), flow=flow_c.detach().numpy(), mask=mask_c.detach().numpy(), factor=np.int32(fu),
+                    out=up.detach().numpy(), grad_out=gup.numpy(), grad_flow=gfl.numpy(), grad_mask=gmk.numpy())
+print("corr pyramid + upsample golden written")

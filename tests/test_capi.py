@@ -18,7 +18,7 @@ from gps_gaussian_amd import _capi
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "gpsgs.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|size_t|const char \*)\s*\*?\s*((?:gsr|cs|gpsgs|fl|up)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|size_t|const char \*)\s*\*?\s*((?:gsr|cs|gpsgs|fl|up|cv|cu)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -95,3 +95,37 @@ def test_loss_oracle_matches_reference_l1_and_ssim_values_and_gradients():
     assert abs(s - float(g["ssim"])) < 1e-6
     np.testing.assert_allclose(gr, g["grad_ssim"], rtol=0, atol=1e-5 * np.abs(g["grad_ssim"]).max())
     np.testing.assert_allclose(np.sign(g["pred"].astype(np.float64) - g["gt"]) / g["pred"].size, g["grad_l1"], atol=1e-9)
+
+
+# ---- row f4: correlation volume + pyramid, multi-level lookup, convex upsampling -------------------------------------------------
+def test_corr_pyramid_oracle_matches_reference_golden():
+    from oracle import corr_oracle as CO
+    z = np.load(os.path.join(GOLDEN, "corr_pyramid_golden.npz"))
+    pyr = CO.build_pyramid(z["fmap1"], z["fmap2"], 4)
+    for l in range(4):
+        assert pyr[l].shape == z["pyr%d" % l].shape
+        np.testing.assert_allclose(pyr[l], z["pyr%d" % l], rtol=2e-5, atol=2e-5)   # the golden is fp32 torch
+    g1, g2 = CO.build_pyramid_backward(z["fmap1"], z["fmap2"], [z["grad_pyr%d" % l] for l in range(4)])
+    np.testing.assert_allclose(g1, z["grad_fmap1"], rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(g2, z["grad_fmap2"], rtol=2e-5, atol=5e-5)
+
+
+def test_multilevel_lookup_oracle_matches_reference_golden():
+    from oracle import corr_oracle as CO
+    z = np.load(os.path.join(GOLDEN, "corr_sampler_golden.npz"))
+    vols = [z["volume%d" % l] for l in range(4)]
+    out = CO.lookup(vols, z["coords"], int(z["radius"]))
+    np.testing.assert_allclose(out, z["out"], rtol=1e-5, atol=1e-5)
+    gv = CO.lookup_backward([v.shape[-1] for v in vols], z["coords"], z["grad_out"], int(z["radius"]))
+    for l in range(4):
+        np.testing.assert_allclose(gv[l], z["grad_volume%d" % l], rtol=1e-5, atol=1e-5)
+
+
+def test_upsample_oracle_matches_reference_golden():
+    from oracle import corr_oracle as CO
+    z = np.load(os.path.join(GOLDEN, "upsample_golden.npz"))
+    f = int(z["factor"])
+    np.testing.assert_allclose(CO.upsample_flow(z["flow"], z["mask"], f), z["out"], rtol=1e-5, atol=1e-5)
+    gf, gm = CO.upsample_flow_backward(z["flow"], z["mask"], z["grad_out"], f)
+    np.testing.assert_allclose(gf, z["grad_flow"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(gm, z["grad_mask"], rtol=1e-5, atol=2e-5)
