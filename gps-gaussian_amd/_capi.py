@@ -10,7 +10,7 @@ SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
-    "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward",
+    "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
 )
 
 GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
@@ -99,7 +99,9 @@ def lib():
     l.cu_upsample_forward.restype = i32
     l.cu_upsample_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.cu_upsample_backward.restype = i32
-    l.cu_upsample_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    l.cu_upsample_backward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    l.cu_upsample_scratch_bytes.restype = sz
+    l.cu_upsample_scratch_bytes.argtypes = [i32, i32, i32, i32]
     if l.gpsgs_abi_version() != 1:
         raise ImportError("gps_gaussian_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = l

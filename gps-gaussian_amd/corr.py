@@ -173,8 +173,8 @@ class _ConvexUpsample(torch.autograd.Function):
         if not flow.is_cuda:
             raise RuntimeError("gps_gaussian_amd: upsample_flow inputs must live on a GPU (no CPU fallback)")
         N, Cc, H, W = flow.shape
-        if mask.shape[0] != N or mask.shape[1] != 9 * factor * factor or tuple(mask.shape[2:]) != (H, W) or not 1 <= Cc <= 4:
-            raise RuntimeError("flow must be [N,C<=4,H,W] and mask [N,9*factor^2,H,W]")
+        if mask.shape[0] != N or mask.shape[1] != 9 * factor * factor or tuple(mask.shape[2:]) != (H, W) or not 1 <= Cc <= 2:
+            raise RuntimeError("flow must be [N,C<=2,H,W] and mask [N,9*factor^2,H,W]")
         fl = flow.detach().to(torch.float32).contiguous()
         mk = mask.detach().to(torch.float32).contiguous()  # AMP hands over an fp16 mask; the softmax is evaluated in fp32
         out = torch.empty((N, Cc, H * factor, W * factor), dtype=torch.float32, device=flow.device)
@@ -197,10 +197,13 @@ class _ConvexUpsample(torch.autograd.Function):
         gm = torch.empty_like(mk) if ctx.needs_input_grad[1] else None
         if gf is None and gm is None:
             return None, None, None
+        scratch = torch.empty((lib.cu_upsample_scratch_bytes(N, Cc, H, W),), dtype=torch.uint8, device=fl.device) if gf is not None else None
         with torch.cuda.device(fl.device):
             rc = lib.cu_upsample_backward(C.c_void_p(fl.data_ptr()), C.c_void_p(mk.data_ptr()), C.c_void_p(g.data_ptr()),
                                           C.c_void_p(gf.data_ptr()) if gf is not None else None,
-                                          C.c_void_p(gm.data_ptr()) if gm is not None else None, N, Cc, H, W, ctx.factor, _stream(fl.device))
+                                          C.c_void_p(gm.data_ptr()) if gm is not None else None,
+                                          C.c_void_p(scratch.data_ptr()) if scratch is not None else None, N, Cc, H, W, ctx.factor,
+                                          _stream(fl.device))
         _capi.check(rc, "cu_upsample_backward")
         return (gf.to(ctx.dtypes[0]) if gf is not None else None, gm.to(ctx.dtypes[1]) if gm is not None else None, None)
 

@@ -31,39 +31,76 @@ template <typename T> __device__ __forceinline__ float rnd(float v);  // round t
 template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 template <> __device__ __forceinline__ float rnd<__half>(float v) { return __half2float(__float2half(v)); }
 
-constexpr int TM = 64, TN = 64, TK = 32;  // workgroup tile; 4 waves, each one 32 x 32 MFMA accumulator
-constexpr int LDS_LD = TM + 1;            // +1 float: the transposing stores of k-contiguous operands stay conflict-free
+constexpr int TK = 32;  // K-chunk staged through LDS per step
 
 // ---- tile engine ------------------------------------------------------------------------------------------------------
-// C[m, n] = sum_k A(m, k) B(k, n) for one (m0, n0) workgroup tile.  fetchA(m, k) / fetchB(k, n) return the operand element (0
-// outside the problem); a_k_contig / b_k_contig say which index is contiguous in memory so the staging loads coalesce.
-// On return acc holds the wave's 32 x 32 tile: register v of lane l is row (v / 4) * 8 + (l / 32) * 4 + v % 4, column l % 32.
-template <bool A_K_CONTIG, bool B_K_CONTIG, typename FA, typename FB>
-__device__ __forceinline__ void tile_gemm(int K, FA fetchA, FB fetchB, float (*As)[LDS_LD], float (*Bs)[LDS_LD], v16f &acc) {
+// C[m, n] = sum_k A(m, k) B(k, n) for one workgroup tile of (64 MT) x (64 NT): 4 waves in a 2 x 2 arrangement, each holding
+// MT x NT accumulator tiles of 32 x 32 (rows wm + 64 i, columns wn + 64 j).  fetchA(m, k) / fetchB(k, n) return the operand
+// element (0 outside the problem); A_K_CONTIG / B_K_CONTIG say which index is contiguous in memory so the staging loads
+// coalesce.  The next K-chunk is fetched into registers while the MFMAs of the current one run (one LDS buffer, two barriers
+// per chunk).  Register v of lane l of an accumulator is row (v / 4) * 8 + (l / 32) * 4 + v % 4, column l % 32.
+template <int MT, int NT, bool A_K_CONTIG, bool B_K_CONTIG, typename FA, typename FB>
+__device__ __forceinline__ void tile_gemm(int K, FA fetchA, FB fetchB, float (*As)[64 * MT + 1], float (*Bs)[64 * NT + 1], v16f (&acc)[MT][NT]) {
+    constexpr int AM = 64 * MT, BN = 64 * NT, NA = TK * AM / 256, NBL = TK * BN / 256;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = (wid & 1) * 32, wn = (wid >> 1) * 32;
 #pragma unroll
-    for (int v = 0; v < 16; v++) acc[v] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += TK) {
-        __syncthreads();
+    for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int e = tid; e < TK * TM; e += 256) {
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[i][j][v] = 0.f;
+    float ra[NA], rb[NBL];
+    auto a_idx = [&](int u, int &kk, int &mm) {
+        const int e = tid + u * 256;
+        if (A_K_CONTIG) { kk = e % TK; mm = e / TK; } else { mm = e % AM; kk = e / AM; }
+    };
+    auto b_idx = [&](int u, int &kk, int &nn) {
+        const int e = tid + u * 256;
+        if (B_K_CONTIG) { kk = e % TK; nn = e / TK; } else { nn = e % BN; kk = e / BN; }
+    };
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
             int kk, mm;
-            if (A_K_CONTIG) { kk = e % TK; mm = e / TK; } else { mm = e % TM; kk = e / TM; }
-            As[kk][mm] = fetchA(mm, k0 + kk);
+            a_idx(u, kk, mm);
+            ra[u] = fetchA(mm, k0 + kk);
         }
 #pragma unroll
-        for (int e = tid; e < TK * TN; e += 256) {
+        for (int u = 0; u < NBL; u++) {
             int kk, nn;
-            if (B_K_CONTIG) { kk = e % TK; nn = e / TK; } else { nn = e % TN; kk = e / TN; }
-            Bs[kk][nn] = fetchB(k0 + kk, nn);
+            b_idx(u, kk, nn);
+            rb[u] = fetchB(k0 + kk, nn);
+        }
+    };
+    load(0);
+    for (int k0 = 0; k0 < K; k0 += TK) {
+        __syncthreads();  // every wave is done reading the previous chunk
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            int kk, mm;
+            a_idx(u, kk, mm);
+            As[kk][mm] = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NBL; u++) {
+            int kk, nn;
+            b_idx(u, kk, nn);
+            Bs[kk][nn] = rb[u];
         }
         __syncthreads();
+        if (k0 + TK < K) load(k0 + TK);  // in flight while the matrix cores work on this chunk
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
-            const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) a[i] = As[kk + (lane >> 5)][wm + 64 * i + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < NT; j++) b[j] = Bs[kk + (lane >> 5)][wn + 64 * j + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
 }
@@ -76,44 +113,49 @@ struct PyrConstPtrs {
     const void *p[4];
 };
 
+constexpr int FWD_MT = 2;  // 128 w1 rows per workgroup: at the reference's 128-wide feature maps F2 is fetched once per (image, row)
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_cv_fwd(const T *__restrict__ f1, const T *__restrict__ f2, PyrPtrs pyr, int D, int H, int W1, int W2,
                                                 int levels, float scale) {
-    __shared__ float As[TK][LDS_LD];
-    __shared__ float Bs[TK][LDS_LD];
+    __shared__ float As[TK][64 * FWD_MT + 1];
+    __shared__ float Bs[TK][64 + 1];
     const int g = blockIdx.z;  // n * H + h
     const int n = g / H, h = g - n * H;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int m0 = blockIdx.y * 64 * FWD_MT, n0 = blockIdx.x * 64;
     const T *a = f1 + ((size_t)n * D * H + h) * W1;  // element (d, w1) at a[d * H * W1 + w1]
     const T *b = f2 + ((size_t)n * D * H + h) * W2;
     const size_t lda = (size_t)H * W1, ldb = (size_t)H * W2;
-    v16f acc;
-    tile_gemm<false, false>(
+    v16f acc[FWD_MT][1];
+    tile_gemm<FWD_MT, 1, false, false>(
         D, [&](int mm, int k) { return (m0 + mm < W1 && k < D) ? ldf(a + (size_t)k * lda + m0 + mm) : 0.f; },
         [&](int k, int nn) { return (n0 + nn < W2 && k < D) ? ldf(b + (size_t)k * ldb + n0 + nn) : 0.f; }, As, Bs, acc);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = n0 + (wid >> 1) * 32 + (lane & 31);  // w2
-    const int row0 = m0 + (wid & 1) * 32 + (lane >> 5) * 4;
     // widths of the pyramid levels: avg_pool2d([1, 2], stride [1, 2]) floors
     int wl[4];
     wl[0] = W2;
 #pragma unroll
     for (int l = 1; l < 4; l++) wl[l] = wl[l - 1] >> 1;
 #pragma unroll
-    for (int v = 0; v < 16; v++) {
-        const int w1 = row0 + (v >> 2) * 8 + (v & 3);
-        float c = rnd<T>(acc[v] * scale);
-        const bool row_ok = w1 < W1;
-        const size_t rowbase = (size_t)g * W1 + w1;
-        if (row_ok && col < W2) stf(reinterpret_cast<T *>(pyr.p[0]) + rowbase * wl[0] + col, c);
-        // level l+1 = 0.5 (even + odd neighbour) of level l: the neighbour sits 2^l lanes away
+    for (int i = 0; i < FWD_MT; i++) {
+        const int row0 = m0 + 64 * i + (wid & 1) * 32 + (lane >> 5) * 4;
 #pragma unroll
-        for (int l = 1; l < 4; l++) {
-            const float o = __shfl_xor(c, 1 << (l - 1), 64);
-            c = rnd<T>(0.5f * (c + o));
-            if (l < levels) {
-                const int cl = col >> l;
-                if (row_ok && (col & ((1 << l) - 1)) == 0 && cl < wl[l]) stf(reinterpret_cast<T *>(pyr.p[l]) + rowbase * wl[l] + cl, c);
+        for (int v = 0; v < 16; v++) {
+            const int w1 = row0 + (v >> 2) * 8 + (v & 3);
+            float c = rnd<T>(acc[i][0][v] * scale);
+            const bool row_ok = w1 < W1;
+            const size_t rowbase = (size_t)g * W1 + w1;
+            if (row_ok && col < W2) stf(reinterpret_cast<T *>(pyr.p[0]) + rowbase * wl[0] + col, c);
+            // level l+1 = 0.5 (even + odd neighbour) of level l: the neighbour sits 2^l lanes away
+#pragma unroll
+            for (int l = 1; l < 4; l++) {
+                const float o = __shfl_xor(c, 1 << (l - 1), 64);
+                c = rnd<T>(0.5f * (c + o));
+                if (l < levels) {
+                    const int cl = col >> l;
+                    if (row_ok && (col & ((1 << l) - 1)) == 0 && cl < wl[l]) stf(reinterpret_cast<T *>(pyr.p[l]) + rowbase * wl[l] + cl, c);
+                }
             }
         }
     }
@@ -135,38 +177,43 @@ __device__ __forceinline__ float fold_grad(const PyrConstPtrs &gp, int levels, s
     return s;
 }
 
+constexpr int BWD_MT = 3;  // 192 feature channels per workgroup: the folded gradient volume (the big operand) is fetched once per GEMM
+
 // grad_f1[d, w1] = scale * sum_w2 F2[d, w2] dC[w1, w2]      (M = d, N = w1, K = w2; both operands contiguous in k)
 // grad_f2[d, w2] = scale * sum_w1 F1[d, w1] dC[w1, w2]      (M = d, N = w2, K = w1; A contiguous in k, B contiguous in n)
 template <typename T, bool WRT_F1>
-__global__ __launch_bounds__(256) void k_cv_bwd(const T *__restrict__ fother, PyrConstPtrs gp, T *__restrict__ gout, int D, int H, int W1, int W2,
+__global__ __launch_bounds__(256, 2) void k_cv_bwd(const T *__restrict__ fother, PyrConstPtrs gp, T *__restrict__ gout, int D, int H, int W1, int W2,
                                                 int levels, float scale) {
-    __shared__ float As[TK][LDS_LD];
-    __shared__ float Bs[TK][LDS_LD];
+    __shared__ float As[TK][64 * BWD_MT + 1];
+    __shared__ float Bs[TK][64 + 1];
     const int g = blockIdx.z;
     const int n = g / H, h = g - n * H;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;  // m = d, n = w1 (WRT_F1) or w2
+    const int m0 = blockIdx.y * 64 * BWD_MT, n0 = blockIdx.x * 64;  // m = d, n = w1 (WRT_F1) or w2
     const int Wk = WRT_F1 ? W2 : W1, Wn = WRT_F1 ? W1 : W2;
     const T *fo = fother + ((size_t)n * D * H + h) * Wk;  // (d, k) at fo[d * H * Wk + k]
     const size_t ldf_ = (size_t)H * Wk;
-    v16f acc;
+    v16f acc[BWD_MT][1];
     auto fa = [&](int mm, int k) { return (m0 + mm < D && k < Wk) ? ldf(fo + (size_t)(m0 + mm) * ldf_ + k) : 0.f; };
     if (WRT_F1) {
-        tile_gemm<true, true>(
+        tile_gemm<BWD_MT, 1, true, true>(
             Wk, fa, [&](int k, int nn) { return (n0 + nn < W1 && k < W2) ? fold_grad<T>(gp, levels, (size_t)g * W1 + n0 + nn, k, W2) : 0.f; }, As, Bs,
             acc);
     } else {
-        tile_gemm<true, false>(
+        tile_gemm<BWD_MT, 1, true, false>(
             Wk, fa, [&](int k, int nn) { return (n0 + nn < W2 && k < W1) ? fold_grad<T>(gp, levels, (size_t)g * W1 + k, n0 + nn, W2) : 0.f; }, As, Bs,
             acc);
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = n0 + (wid >> 1) * 32 + (lane & 31);
-    const int row0 = m0 + (wid & 1) * 32 + (lane >> 5) * 4;
     T *o = gout + ((size_t)n * D * H + h) * Wn;
 #pragma unroll
-    for (int v = 0; v < 16; v++) {
-        const int d = row0 + (v >> 2) * 8 + (v & 3);
-        if (d < D && col < Wn) stf(o + (size_t)d * H * Wn + col, acc[v] * scale);
+    for (int i = 0; i < BWD_MT; i++) {
+        const int row0 = m0 + 64 * i + (wid & 1) * 32 + (lane >> 5) * 4;
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int d = row0 + (v >> 2) * 8 + (v & 3);
+            if (d < D && col < Wn) stf(o + (size_t)d * H * Wn + col, acc[i][0][v] * scale);
+        }
     }
 }
 
@@ -276,81 +323,91 @@ __global__ __launch_bounds__(256) void k_up_fwd(const float *__restrict__ flow, 
     }
 }
 
-// grad_mask: per fine pixel p = softmax, u_k = sum_c g[c] f flow_c[k]; dlogit_k = p_k (u_k - sum_j p_j u_j)
-__global__ __launch_bounds__(256) void k_up_bwd_mask(const float *__restrict__ flow, const float *__restrict__ mask, const float *__restrict__ gout,
-                                                     float *__restrict__ gmask, int N, int C, int H, int W, int f) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int WF = W * f, HF = H * f;
-    const size_t total = (size_t)N * HF * WF;
-    if (t >= total) return;
-    const int x = (int)(t % WF), y = (int)((t / WF) % HF), n = (int)(t / ((size_t)WF * HF));
-    const int w = x / f, j = x - w * f, h = y / f, i = y - h * f;
+// Backward.  Per fine pixel: p = softmax(9 logits), u_k = sum_c g_c * (f * flow_c at tap k); dlogit_k = p_k (u_k - sum_j p_j u_j).
+// The flow gradient needs, per coarse cell and tap, S[k][c] = sum over the cell's f^2 fine pixels of p_k g_c; the cell (hh, ww)
+// then gathers f * sum_k S[k][c] of its 9 neighbours (k_up_bwd_flow): fixed summation order, no atomics.
+// Workgroup = 64 coarse columns x 4 groups that split the f^2 fine pixels: every mask / grad_mask access is coalesced along w.
+__global__ __launch_bounds__(256) void k_up_bwd_cells(const float *__restrict__ flow, const float *__restrict__ mask, const float *__restrict__ gout,
+                                                      float *__restrict__ gmask, float *__restrict__ S, int C, int H, int W, int f) {
+    __shared__ float red[3][18][64];
+    const int wq = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int w = blockIdx.x * 64 + wq, h = blockIdx.y, n = blockIdx.z;
+    const bool in = w < W;
+    const int WF = W * f, HF = H * f, ff = f * f;
     const size_t hw = (size_t)H * W;
-    const size_t moff = ((size_t)n * 9 * f * f + (size_t)i * f + j) * hw + (size_t)h * W + w;
-    float p[9], u[9], mx = -INFINITY;
+    float tap[2][9], acc[2][9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        p[k] = mask[moff + (size_t)k * f * f * hw];
-        mx = fmaxf(mx, p[k]);
-        u[k] = 0.f;
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        p[k] = expf(p[k] - mx);
-        den += p[k];
-    }
-    const float inv = 1.f / den;
-    for (int c = 0; c < C; c++) {
-        const float gc = gout[(((size_t)n * C + c) * HF + y) * WF + x];
-        const float *fl = flow + ((size_t)n * C + c) * hw;
+    for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const int hh = h + k / 3 - 1, ww = w + k % 3 - 1;
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W) u[k] += gc * ((float)f * fl[(size_t)hh * W + ww]);
+            tap[c][k] = (in && c < C && hh >= 0 && hh < H && ww >= 0 && ww < W) ? (float)f * flow[((size_t)n * C + c) * hw + (size_t)hh * W + ww] : 0.f;
+            acc[c][k] = 0.f;
+        }
+    if (in) {
+        for (int ij = grp; ij < ff; ij += 4) {
+            const int i = ij / f, j = ij - i * f;
+            const size_t moff = ((size_t)n * 9 * ff + ij) * hw + (size_t)h * W + w;
+            float p[9], mx = -INFINITY, den = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                p[k] = mask[moff + (size_t)k * ff * hw];
+                mx = fmaxf(mx, p[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                p[k] = expf(p[k] - mx);
+                den += p[k];
+            }
+            const float inv = 1.f / den;
+            const size_t goff = ((size_t)n * C * HF + (size_t)h * f + i) * WF + (size_t)w * f + j;
+            const float g0 = gout[goff], g1 = C > 1 ? gout[goff + (size_t)HF * WF] : 0.f;
+            float dot = 0.f, u[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                p[k] *= inv;
+                u[k] = g0 * tap[0][k] + g1 * tap[1][k];
+                dot += p[k] * u[k];
+                acc[0][k] += p[k] * g0;
+                acc[1][k] += p[k] * g1;
+            }
+            if (gmask) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) gmask[moff + (size_t)k * ff * hw] = p[k] * (u[k] - dot);
+            }
         }
     }
-    float dot = 0.f;
+    if (!S) return;
+    if (grp > 0) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        p[k] *= inv;
-        dot += p[k] * u[k];
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int k = 0; k < 9; k++) red[grp - 1][c * 9 + k][wq] = acc[c][k];
     }
+    __syncthreads();
+    if (grp == 0 && in) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) gmask[moff + (size_t)k * f * f * hw] = p[k] * (u[k] - dot);
-}
-
-// grad_flow[n, c, hh, ww] = f * sum over the 9 coarse cells (h, w) = (hh - dy, ww - dx) and their f^2 fine pixels of p_k g
-// (a gather: one thread per coarse flow element, fixed summation order, no atomics)
-__global__ __launch_bounds__(256) void k_up_bwd_flow(const float *__restrict__ mask, const float *__restrict__ gout, float *__restrict__ gflow, int N,
-                                                     int C, int H, int W, int f) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // (n * H + hh) * W + ww
-    const size_t total = (size_t)N * H * W;
-    if (t >= total) return;
-    const int ww = (int)(t % W), hh = (int)((t / W) % H), n = (int)(t / ((size_t)W * H));
-    const int WF = W * f, HF = H * f;
-    const size_t hw = (size_t)H * W;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // C <= 4
-    for (int k = 0; k < 9; k++) {
-        const int h = hh - (k / 3 - 1), w = ww - (k % 3 - 1);
-        if (h < 0 || h >= H || w < 0 || w >= W) continue;
-        for (int i = 0; i < f; i++)
-            for (int j = 0; j < f; j++) {
-                const size_t moff = ((size_t)n * 9 * f * f + (size_t)i * f + j) * hw + (size_t)h * W + w;
-                float mx = -INFINITY, den = 0.f, pk = 0.f;
+        for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int q = 0; q < 9; q++) mx = fmaxf(mx, mask[moff + (size_t)q * f * f * hw]);
-#pragma unroll
-                for (int q = 0; q < 9; q++) {
-                    const float e = expf(mask[moff + (size_t)q * f * f * hw] - mx);
-                    den += e;
-                    if (q == k) pk = e;
-                }
-                pk /= den;
-                for (int c = 0; c < C; c++) acc[c] += pk * gout[(((size_t)n * C + c) * HF + (size_t)h * f + i) * WF + (size_t)w * f + j];
+            for (int k = 0; k < 9; k++) {
+                const float v = ((acc[c][k] + red[0][c * 9 + k][wq]) + red[1][c * 9 + k][wq]) + red[2][c * 9 + k][wq];
+                if (c < C) S[(((size_t)n * 9 + k) * C + c) * hw + (size_t)h * W + w] = v;
             }
     }
-    for (int c = 0; c < C; c++) gflow[((size_t)n * C + c) * hw + (size_t)hh * W + ww] = (float)f * acc[c];
+}
+
+__global__ __launch_bounds__(256) void k_up_bwd_flow(const float *__restrict__ S, float *__restrict__ gflow, int N, int C, int H, int W, int f) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((n * C + c) * H + hh) * W + ww
+    const size_t hw = (size_t)H * W;
+    if (t >= (size_t)N * C * hw) return;
+    const int ww = (int)(t % W), hh = (int)((t / W) % H), c = (int)((t / hw) % C), n = (int)(t / (hw * C));
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int h = hh - (k / 3 - 1), w = ww - (k % 3 - 1);
+        if (h >= 0 && h < H && w >= 0 && w < W) s += S[(((size_t)n * 9 + k) * C + c) * hw + (size_t)h * W + w];
+    }
+    gflow[t] = (float)f * s;
 }
 
 }  // namespace
@@ -369,7 +426,7 @@ extern "C" int cv_build_forward(const void *fmap1, const void *fmap2, void *cons
         pp.p[l] = l < levels ? pyramid[l] : nullptr;
         if (l < levels && !pp.p[l] && (W2 >> l) > 0) return GPSGS_E_INVALID;
     }
-    const dim3 grid((W2 + TN - 1) / TN, (W1 + TM - 1) / TM, N * H);
+    const dim3 grid((W2 + 63) / 64, (W1 + 64 * FWD_MT - 1) / (64 * FWD_MT), N * H);
     const float scale = 1.0f / sqrtf((float)D);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == 0)
@@ -389,14 +446,14 @@ extern "C" int cv_build_backward(const void *fmap1, const void *fmap2, const voi
     const float scale = 1.0f / sqrtf((float)D);
     hipStream_t s = (hipStream_t)stream;
     if (grad_fmap1 && W1 > 0) {
-        const dim3 grid((W1 + TN - 1) / TN, (D + TM - 1) / TM, N * H);
+        const dim3 grid((W1 + 63) / 64, (D + 64 * BWD_MT - 1) / (64 * BWD_MT), N * H);
         if (dtype == 0)
             hipLaunchKernelGGL((k_cv_bwd<float, true>), grid, dim3(256), 0, s, (const float *)fmap2, gp, (float *)grad_fmap1, D, H, W1, W2, levels, scale);
         else
             hipLaunchKernelGGL((k_cv_bwd<__half, true>), grid, dim3(256), 0, s, (const __half *)fmap2, gp, (__half *)grad_fmap1, D, H, W1, W2, levels, scale);
     }
     if (grad_fmap2 && W2 > 0) {
-        const dim3 grid((W2 + TN - 1) / TN, (D + TM - 1) / TM, N * H);
+        const dim3 grid((W2 + 63) / 64, (D + 64 * BWD_MT - 1) / (64 * BWD_MT), N * H);
         if (dtype == 0)
             hipLaunchKernelGGL((k_cv_bwd<float, false>), grid, dim3(256), 0, s, (const float *)fmap1, gp, (float *)grad_fmap2, D, H, W1, W2, levels, scale);
         else
@@ -454,18 +511,23 @@ extern "C" int cu_upsample_forward(const float *flow, const float *mask, float *
     return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
 }
 
-extern "C" int cu_upsample_backward(const float *flow, const float *mask, const float *grad_out, float *grad_flow, float *grad_mask, int N, int C, int H,
-                                    int W, int factor, void *stream) {
-    if (N < 0 || C < 1 || C > 4 || H < 0 || W < 0 || factor < 1 || factor > 16) return GPSGS_E_INVALID;
-    const size_t total = (size_t)N * H * factor * W * factor;
+extern "C" size_t cu_upsample_scratch_bytes(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)N * 9 * C * H * W * sizeof(float);
+}
+
+extern "C" int cu_upsample_backward(const float *flow, const float *mask, const float *grad_out, float *grad_flow, float *grad_mask, void *scratch,
+                                    int N, int C, int H, int W, int factor, void *stream) {
+    if (N < 0 || C < 1 || C > 2 || H < 0 || W < 0 || factor < 1 || factor > 16) return GPSGS_E_INVALID;
+    const size_t total = (size_t)N * H * W;
     if (total == 0) return GPSGS_OK;
-    if (!flow || !mask || !grad_out || (!grad_flow && !grad_mask)) return GPSGS_E_INVALID;
+    if (!flow || !mask || !grad_out || (!grad_flow && !grad_mask) || (grad_flow && !scratch) || H > 65535 || N > 65535) return GPSGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    if (grad_mask)
-        hipLaunchKernelGGL(k_up_bwd_mask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, flow, mask, grad_out, grad_mask, N, C, H, W, factor);
+    float *S = grad_flow ? static_cast<float *>(scratch) : nullptr;
+    hipLaunchKernelGGL(k_up_bwd_cells, dim3((W + 63) / 64, H, N), dim3(256), 0, s, flow, mask, grad_out, grad_mask, S, C, H, W, factor);
     if (grad_flow) {
-        const size_t tf = (size_t)N * H * W;
-        hipLaunchKernelGGL(k_up_bwd_flow, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, s, mask, grad_out, grad_flow, N, C, H, W, factor);
+        const size_t tf = total * C;
+        hipLaunchKernelGGL(k_up_bwd_flow, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, s, S, grad_flow, N, C, H, W, factor);
     }
     return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
 }

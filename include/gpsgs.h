@@ -206,10 +206,13 @@ int cs_lookup_forward(const void *const *pyramid, const float *coords, void *out
 /* writes (zero-fills + taps) every grad_pyramid[l][N,H1,W1,W2>>l] */
 int cs_lookup_backward(const float *coords, const void *grad_out, void *const *grad_pyramid, int N, int H1, int W1, int W2, int levels,
                        int radius, int dtype, void *stream);
-/* flow[N,C,H,W] (C <= 4), mask[N,9*f*f,H,W] logits, out[N,C,f*H,f*W]; fp32. */
+/* flow[N,C,H,W] (C <= 4 forward, <= 2 backward: the reference upsamples a 2-channel flow), mask[N,9*f*f,H,W] logits,
+ * out[N,C,f*H,f*W]; fp32.  The backward needs cu_upsample_scratch_bytes() of device scratch when grad_flow is requested
+ * (per coarse cell and tap: the sums of softmax weight x upstream gradient); grad_flow / grad_mask may each be NULL. */
 int cu_upsample_forward(const float *flow, const float *mask, float *out, int N, int C, int H, int W, int factor, void *stream);
-int cu_upsample_backward(const float *flow, const float *mask, const float *grad_out, float *grad_flow, float *grad_mask, int N, int C,
-                         int H, int W, int factor, void *stream);
+size_t cu_upsample_scratch_bytes(int N, int C, int H, int W);
+int cu_upsample_backward(const float *flow, const float *mask, const float *grad_out, float *grad_flow, float *grad_mask, void *scratch,
+                         int N, int C, int H, int W, int factor, void *stream);
 
 #ifdef __cplusplus
 }
