@@ -30,6 +30,71 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_
 VALU_PEAK_TLANEOPS = 78.6   # 157.3 TFLOP/s fp32 vector = 78.6 T FMA lane-ops/s
 
 
+def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, steps=10):
+    """Secondary measurement (never part of `value`): the non-network part of one stage-2 training iteration
+    (/root/reference/train_stage2.py:65-72,83) with the reference's batch of 4 stereo pairs per GPU: pts2render (fused
+    mask-compaction + pack, then one raster forward per pair) -> 0.8 L1 + 0.2 (1 - SSIM) -> backward down to the per-pixel
+    Gaussian maps, followed by the ONE exchange step of data-parallel stage-2 training: a mean all-reduce of the network's
+    5,144,408 fp32 gradients (20.6 MB, one RCCL bucket; no-op on one GPU).  The RAFT-Stereo / regressor networks themselves
+    are out of scope and not executed.  Every rank always reaches every collective: a local failure is
+    agreed on through a MIN all-reduce before any timed collective is issued."""
+    import torch
+    import torch.distributed as dist
+    from gps_gaussian_amd import loss as L
+    from gps_gaussian_amd import render_api
+    ok, err, step = 1, None, None
+    try:
+        B, res = batch, args.res
+        rres = args.render_res or args.res
+        cam = sample["novel_view"]
+        data = {}
+        for v in ("lmain", "rmain"):
+            d = sample[v]
+            rep = lambda a, *r: torch.from_numpy(a).to(dev)[None].repeat(B, *r)
+            data[v] = dict(img=rep(d["img"], 1, 1, 1), xyz=rep(d["xyz"], 1, 1).requires_grad_(True), pts_valid=rep(d["pts_valid"], 1),
+                           rot_maps=rep(d["rot_maps"], 1, 1, 1).requires_grad_(True), scale_maps=rep(d["scale_maps"], 1, 1, 1).requires_grad_(True),
+                           opacity_maps=rep(d["opacity_maps"], 1, 1, 1).requires_grad_(True))
+        data["novel_view"] = dict(FovX=torch.tensor([float(cam["FovX"])] * B), FovY=torch.tensor([float(cam["FovY"])] * B),
+                                  width=torch.tensor([rres] * B), height=torch.tensor([rres] * B),
+                                  world_view_transform=torch.from_numpy(cam["world_view_transform"])[None].repeat(B, 1, 1).pin_memory(),
+                                  full_proj_transform=torch.from_numpy(cam["full_proj_transform"])[None].repeat(B, 1, 1).pin_memory(),
+                                  camera_center=torch.from_numpy(cam["camera_center"])[None].repeat(B, 1))
+        gt = torch.rand(B, 3, rres, rres, device=dev)
+        net = [torch.nn.Parameter(torch.zeros(5_144_408, device=dev))]  # stands in for the network's parameters
+        net[0].grad = torch.randn_like(net[0])
+        reducer = D.GradAllReducer(net)
+
+        def step():
+            for v in ("lmain", "rmain"):
+                for k in ("xyz", "rot_maps", "scale_maps", "opacity_maps"):
+                    data[v][k].grad = None
+            img = render_api.pts2render(data, [0, 0, 0])["novel_view"]["img_pred"]
+            L.stage2_photometric_loss(img, gt).backward()
+            reducer()
+
+        def local_step():  # the same without the collective: warm-up / self-check before anything is timed
+            img = render_api.pts2render(data, [0, 0, 0])["novel_view"]["img_pred"]
+            L.stage2_photometric_loss(img, gt).backward()
+
+        local_step(); local_step()
+        torch.cuda.synchronize(dev)
+    except Exception as e:  # noqa: BLE001
+        ok, err = 0, repr(e)[:300]
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok_all = int(flag.item())
+    else:
+        ok_all = ok
+    if not ok_all:
+        return {"error": err or "another rank failed"}
+    el = timed(step, steps, 2)
+    return {"iters_per_s": round(steps / el, 2), "stereo_pairs_per_s": round(world * batch * steps / el, 1), "ms_per_iter": round(el / steps * 1e3, 3),
+            "batch_per_gpu": batch, "n_gpus": world, "render": "%dx%d" % (rres, rres),
+            "includes": "pts2render (fused pack + %d raster forwards) + L1/SSIM loss + backward to the per-pixel maps + mean all-reduce of "
+                        "20.6 MB of network gradients (RCCL); networks not executed" % batch}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,9 +118,13 @@ def main():
     rank, local_rank, world = D.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    # test hooks (a 1-GPU box can still exercise the multi-rank code path): all ranks on device 0, gloo instead of RCCL
+    if os.environ.get("GPSGS_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("GPSGS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init(backend="nccl", device=dev)  # "nccl" is RCCL on ROCm; no-op at world size 1
+    D.init(backend=backend, device=dev)  # "nccl" is RCCL on ROCm; no-op at world size 1
     _capi.lib()  # fail loudly if the HIP library is missing
 
     # ---- synthetic workload: one stereo pair per rank (different pose per rank), resident in HBM ------------------
@@ -139,6 +208,9 @@ def main():
     os.environ["GPSGS_CHECK"] = "sync"
     torch.cuda.synchronize(dev)
 
+    # ---- secondary: the hot path inside one stage-2 training iteration (BASELINE config 4: batch = 4 stereo pairs per GPU) ----
+    stage2 = stage2_leg(args, s, dev, rank, local_rank, world, D, timed)
+
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------------
     NB = (((W + 7) // 8 + 3) // 4 * 4) * ((H + 7) // 8)  # 8x8-pixel bins (one wave64 each), DESIGN.md section 2
     npix = W * H
@@ -207,6 +279,7 @@ def main():
             "forward_only_views_per_s": round(world * args.steps / el_fwd, 2),
             "deferred_check_views_per_s": {"fwd_bwd": round(world * args.steps / el_def, 2), "fwd": round(world * args.steps / el_fwd_def, 2)},
             "stages": per_stage,
+            "stage2_path": stage2,
         }
         print(json.dumps(line))
     D.shutdown()
