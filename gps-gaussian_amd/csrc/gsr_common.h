@@ -21,7 +21,7 @@
 //   goff[P], gscan_part[P/1024+1]   exclusive prefix of every Gaussian's bin-rect area (its slots in inst_pos), kept as
 //                  (prefix inside its 1024-block, prefix of the blocks): both fall out of the forward for free
 //   inst_pos[cap]  for (Gaussian, k-th bin of its rect): position of that instance in point_list, or ~0
-//   inst_grad[cap] 48-byte records of per-INSTANCE partial sums {dcolor rgb, dmean2D xy | dconic xx xy yy, dopacity}
+//   inst_grad[cap] 64-byte (48 used) records of per-INSTANCE partial sums {dcolor rgb, dmean2D xy | dconic xx xy yy, dopacity}
 //                  written with plain coalesced stores by the compositing backward and gathered per Gaussian by
 //                  k_preprocess_bwd: no float atomics at all (measured 20-30 Mops/ms on MI355X, tools/ubench/) and the
 //                  gradients are bit-reproducible run to run
@@ -45,12 +45,13 @@ struct __attribute__((aligned(16))) GsrSplat {
 };
 static_assert(sizeof(GsrSplat) == 48, "splat record must be 48 bytes");
 
-struct __attribute__((aligned(16))) GsrGradAcc {
+struct __attribute__((aligned(64))) GsrGradAcc {
     float dr, dg, db, dmx;    // dL/dcolor, dL/dmean2D.x (NDC-scaled)
     float dmy, cxx, cxy, cyy; // dL/dmean2D.y, dL/dconic (xy holds HALF the true off-diagonal gradient, like upstream)
     float dop, pad0, pad1, pad2;
+    float pad3[4];            // 64-byte records: the per-Gaussian gather then touches exactly one 64-byte sector per record
 };
-static_assert(sizeof(GsrGradAcc) == 48, "grad record must be 48 bytes");
+static_assert(sizeof(GsrGradAcc) == 64, "grad record must be 64 bytes");
 
 struct GsrLayout {
     size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, keys, point_list, final_T, n_contrib;
