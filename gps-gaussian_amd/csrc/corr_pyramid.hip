@@ -35,13 +35,14 @@ constexpr int TK = 32;  // K-chunk staged through LDS per step
 
 // ---- tile engine ------------------------------------------------------------------------------------------------------
 // C[m, n] = sum_k A(m, k) B(k, n) for one workgroup tile of (64 MT) x (64 NT): 4 waves in a 2 x 2 arrangement, each holding
-// MT x NT accumulator tiles of 32 x 32 (rows wm + 64 i, columns wn + 64 j).  fetchA(m, k) / fetchB(k, n) return the operand
-// element (0 outside the problem); A_K_CONTIG / B_K_CONTIG say which index is contiguous in memory so the staging loads
-// coalesce.  The next K-chunk is fetched into registers while the MFMAs of the current one run (one LDS buffer, two barriers
-// per chunk).  Register v of lane l of an accumulator is row (v / 4) * 8 + (l / 32) * 4 + v % 4, column l % 32.
+// MT x NT accumulator tiles of 32 x 32 (rows wm + 64 i, columns wn + 64 j).  fetchA(m, k) / fetchB(k, n) return FOUR operand
+// elements (0 outside the problem) starting at that position and running along the operand's contiguous memory index --
+// k if A_K_CONTIG / B_K_CONTIG, else m / n -- so the staging loads are 16-byte (fp32) or 8-byte (fp16) vectors that coalesce.
+// The next K-chunk is fetched into registers while the MFMAs of the current one run (one LDS buffer, two barriers per
+// chunk).  Register v of lane l of an accumulator is row (v / 4) * 8 + (l / 32) * 4 + v % 4, column l % 32.
 template <int MT, int NT, bool A_K_CONTIG, bool B_K_CONTIG, typename FA, typename FB>
 __device__ __forceinline__ void tile_gemm(int K, FA fetchA, FB fetchB, float (*As)[64 * MT + 1], float (*Bs)[64 * NT + 1], v16f (&acc)[MT][NT]) {
-    constexpr int AM = 64 * MT, BN = 64 * NT, NA = TK * AM / 256, NBL = TK * BN / 256;
+    constexpr int AM = 64 * MT, BN = 64 * NT, NA = TK * AM / 1024, NBL = TK * BN / 1024;  // float4 groups per thread
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = (wid & 1) * 32, wn = (wid >> 1) * 32;
 #pragma unroll
@@ -50,14 +51,14 @@ __device__ __forceinline__ void tile_gemm(int K, FA fetchA, FB fetchB, float (*A
         for (int j = 0; j < NT; j++)
 #pragma unroll
             for (int v = 0; v < 16; v++) acc[i][j][v] = 0.f;
-    float ra[NA], rb[NBL];
-    auto a_idx = [&](int u, int &kk, int &mm) {
+    float4 ra[NA], rb[NBL];
+    auto a_idx = [&](int u, int &kk, int &mm) {  // first element of group u of this thread
         const int e = tid + u * 256;
-        if (A_K_CONTIG) { kk = e % TK; mm = e / TK; } else { mm = e % AM; kk = e / AM; }
+        if (A_K_CONTIG) { kk = (e % (TK / 4)) * 4; mm = e / (TK / 4); } else { mm = (e % (AM / 4)) * 4; kk = e / (AM / 4); }
     };
     auto b_idx = [&](int u, int &kk, int &nn) {
         const int e = tid + u * 256;
-        if (B_K_CONTIG) { kk = e % TK; nn = e / TK; } else { nn = e % BN; kk = e / BN; }
+        if (B_K_CONTIG) { kk = (e % (TK / 4)) * 4; nn = e / (TK / 4); } else { nn = (e % (BN / 4)) * 4; kk = e / (BN / 4); }
     };
     auto load = [&](int k0) {
 #pragma unroll
@@ -80,13 +81,15 @@ __device__ __forceinline__ void tile_gemm(int K, FA fetchA, FB fetchB, float (*A
         for (int u = 0; u < NA; u++) {
             int kk, mm;
             a_idx(u, kk, mm);
-            As[kk][mm] = ra[u];
+            if (A_K_CONTIG) { As[kk][mm] = ra[u].x; As[kk + 1][mm] = ra[u].y; As[kk + 2][mm] = ra[u].z; As[kk + 3][mm] = ra[u].w; }
+            else { As[kk][mm] = ra[u].x; As[kk][mm + 1] = ra[u].y; As[kk][mm + 2] = ra[u].z; As[kk][mm + 3] = ra[u].w; }
         }
 #pragma unroll
         for (int u = 0; u < NBL; u++) {
             int kk, nn;
             b_idx(u, kk, nn);
-            Bs[kk][nn] = rb[u];
+            if (B_K_CONTIG) { Bs[kk][nn] = rb[u].x; Bs[kk + 1][nn] = rb[u].y; Bs[kk + 2][nn] = rb[u].z; Bs[kk + 3][nn] = rb[u].w; }
+            else { Bs[kk][nn] = rb[u].x; Bs[kk][nn + 1] = rb[u].y; Bs[kk][nn + 2] = rb[u].z; Bs[kk][nn + 3] = rb[u].w; }
         }
         __syncthreads();
         if (k0 + TK < K) load(k0 + TK);  // in flight while the matrix cores work on this chunk
@@ -103,6 +106,25 @@ __device__ __forceinline__ void tile_gemm(int K, FA fetchA, FB fetchB, float (*A
                 for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+}
+
+// four consecutive elements p[0..3] of which the first `n` (0..4) exist; `vec` = the 4-element vector load is aligned and allowed
+template <typename T> __device__ __forceinline__ float4 ld4(const T *p, int n, bool vec);
+template <> __device__ __forceinline__ float4 ld4<float>(const float *p, int n, bool vec) {
+    if (vec && n >= 4) return *reinterpret_cast<const float4 *>(p);
+    return make_float4(n > 0 ? p[0] : 0.f, n > 1 ? p[1] : 0.f, n > 2 ? p[2] : 0.f, n > 3 ? p[3] : 0.f);
+}
+template <> __device__ __forceinline__ float4 ld4<__half>(const __half *p, int n, bool vec) {
+    if (vec && n >= 4) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p);
+        const float2 lo = __half22float2(*reinterpret_cast<const __half2 *>(&r.x)), hi = __half22float2(*reinterpret_cast<const __half2 *>(&r.y));
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    return make_float4(n > 0 ? __half2float(p[0]) : 0.f, n > 1 ? __half2float(p[1]) : 0.f, n > 2 ? __half2float(p[2]) : 0.f,
+                       n > 3 ? __half2float(p[3]) : 0.f);
+}
+template <typename T> __device__ __forceinline__ bool vec4_ok(const T *base, int row_len) {  // every row start and every 4-group aligned
+    return (row_len & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & (4 * sizeof(T) - 1)) == 0;
 }
 
 // ---- forward: volume + pyramid ----------------------------------------------------------------------------------------
@@ -127,9 +149,10 @@ __global__ __launch_bounds__(256) void k_cv_fwd(const T *__restrict__ f1, const 
     const T *b = f2 + ((size_t)n * D * H + h) * W2;
     const size_t lda = (size_t)H * W1, ldb = (size_t)H * W2;
     v16f acc[FWD_MT][1];
+    const bool va = vec4_ok(f1, W1), vb = vec4_ok(f2, W2);
     tile_gemm<FWD_MT, 1, false, false>(
-        D, [&](int mm, int k) { return (m0 + mm < W1 && k < D) ? ldf(a + (size_t)k * lda + m0 + mm) : 0.f; },
-        [&](int k, int nn) { return (n0 + nn < W2 && k < D) ? ldf(b + (size_t)k * ldb + n0 + nn) : 0.f; }, As, Bs, acc);
+        D, [&](int mm, int k) { return ld4(a + (size_t)k * lda + m0 + mm, k < D ? W1 - (m0 + mm) : 0, va); },
+        [&](int k, int nn) { return ld4(b + (size_t)k * ldb + n0 + nn, k < D ? W2 - (n0 + nn) : 0, vb); }, As, Bs, acc);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = n0 + (wid >> 1) * 32 + (lane & 31);  // w2
     // widths of the pyramid levels: avg_pool2d([1, 2], stride [1, 2]) floors
@@ -193,15 +216,39 @@ __global__ __launch_bounds__(256, 2) void k_cv_bwd(const T *__restrict__ fother,
     const T *fo = fother + ((size_t)n * D * H + h) * Wk;  // (d, k) at fo[d * H * Wk + k]
     const size_t ldf_ = (size_t)H * Wk;
     v16f acc[BWD_MT][1];
-    auto fa = [&](int mm, int k) { return (m0 + mm < D && k < Wk) ? ldf(fo + (size_t)(m0 + mm) * ldf_ + k) : 0.f; };
-    if (WRT_F1) {
-        tile_gemm<BWD_MT, 1, true, true>(
-            Wk, fa, [&](int k, int nn) { return (n0 + nn < W1 && k < W2) ? fold_grad<T>(gp, levels, (size_t)g * W1 + n0 + nn, k, W2) : 0.f; }, As, Bs,
-            acc);
-    } else {
-        tile_gemm<BWD_MT, 1, true, false>(
-            Wk, fa, [&](int k, int nn) { return (n0 + nn < W2 && k < W1) ? fold_grad<T>(gp, levels, (size_t)g * W1 + k, n0 + nn, W2) : 0.f; }, As, Bs,
-            acc);
+    const bool vf = vec4_ok(fother, Wk);
+    auto fa = [&](int mm, int k) { return ld4(fo + (size_t)(m0 + mm) * ldf_ + k, m0 + mm < D ? Wk - k : 0, vf); };  // 4 along k
+    // four consecutive w2 of one volume row, folded from the per-level gradients
+    bool vg = (W2 & 7) == 0;
+    for (int l = 0; l < 4; l++) vg = vg && (l >= levels || !gp.p[l] || (reinterpret_cast<uintptr_t>(gp.p[l]) & 15) == 0);
+    auto fold4 = [&](size_t rowbase, int w2, bool row_ok) {
+        if (!row_ok || w2 >= W2) return make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!vg || w2 + 3 >= W2)
+            return make_float4(fold_grad<T>(gp, levels, rowbase, w2, W2), w2 + 1 < W2 ? fold_grad<T>(gp, levels, rowbase, w2 + 1, W2) : 0.f,
+                               w2 + 2 < W2 ? fold_grad<T>(gp, levels, rowbase, w2 + 2, W2) : 0.f,
+                               w2 + 3 < W2 ? fold_grad<T>(gp, levels, rowbase, w2 + 3, W2) : 0.f);
+        // W2 % 8 == 0 and w2 % 4 == 0: every level's window is complete and its loads are aligned; same sums as fold_grad
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gp.p[0]) r = ld4(reinterpret_cast<const T *>(gp.p[0]) + rowbase * W2 + w2, 4, true);
+        if (levels > 1 && gp.p[1]) {
+            const T *q = reinterpret_cast<const T *>(gp.p[1]) + rowbase * (W2 >> 1) + (w2 >> 1);
+            const float q0 = ldf(q), q1 = ldf(q + 1);
+            r.x += 0.5f * q0; r.y += 0.5f * q0; r.z += 0.5f * q1; r.w += 0.5f * q1;
+        }
+        if (levels > 2 && gp.p[2]) {
+            const float q0 = ldf(reinterpret_cast<const T *>(gp.p[2]) + rowbase * (W2 >> 2) + (w2 >> 2));
+            r.x += 0.25f * q0; r.y += 0.25f * q0; r.z += 0.25f * q0; r.w += 0.25f * q0;
+        }
+        if (levels > 3 && gp.p[3]) {
+            const float q0 = ldf(reinterpret_cast<const T *>(gp.p[3]) + rowbase * (W2 >> 3) + (w2 >> 3));
+            r.x += 0.125f * q0; r.y += 0.125f * q0; r.z += 0.125f * q0; r.w += 0.125f * q0;
+        }
+        return r;
+    };
+    if (WRT_F1) {  // B(k = w2, n = w1): 4 along k = 4 consecutive w2 of row w1
+        tile_gemm<BWD_MT, 1, true, true>(Wk, fa, [&](int k, int nn) { return fold4((size_t)g * W1 + n0 + nn, k, n0 + nn < W1); }, As, Bs, acc);
+    } else {       // B(k = w1, n = w2): 4 along n = 4 consecutive w2 of row k
+        tile_gemm<BWD_MT, 1, true, false>(Wk, fa, [&](int k, int nn) { return fold4((size_t)g * W1 + k, n0 + nn, k < W1); }, As, Bs, acc);
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = n0 + (wid >> 1) * 32 + (lane & 31);
