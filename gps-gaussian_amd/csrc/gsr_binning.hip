@@ -131,33 +131,36 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     }
 }
 
-__global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats,
+__global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
                                                             uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
                                                             const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
                                                             const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos) {
     if (hdr->overflow) return;
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
-    uint32_t lo = 0, hi = 0;
+    uint32_t lo = 0, hi = 0, mask = 0;
     uint64_t key = 0;
     GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
     if (i < P) {
+        mask = hitmask[i];  // the exact ellipse/bin tests of this Gaussian's rect, done once by k_preprocess
         const float4 *rec = reinterpret_cast<const float4 *>(splats + i);
         const float4 c = rec[2];
         lo = __float_as_uint(c.z);
         hi = __float_as_uint(c.w);
         key = ((uint64_t)__float_as_uint(c.y) << 32) | (uint32_t)i;
-        if ((hi & 0xffff) > (lo & 0xffff)) {  // listed somewhere: the same predicate k_preprocess counted with
-            const float4 a = rec[0], b = rec[1];
-            hit = gsr_hit_setup(a.x, a.y, a.z, a.w, b.x, b.y);
+        if ((hi & 0xffff) > (lo & 0xffff)) {  // listed somewhere
+            const uint32_t area = ((hi & 0xffff) - (lo & 0xffff)) * ((hi >> 16) - (lo >> 16));
+            if (area > 32u) {  // rect too large for the cached mask: the predicate k_preprocess counted with, re-evaluated per cell
+                const float4 a = rec[0], b = rec[1];
+                hit = gsr_hit_setup(a.x, a.y, a.z, a.w, b.x, b.y);
+            }
             if (inst_pos) {  // training: mark this Gaussian's instance slots "no record yet" (replaces a 4*cap-byte memset)
                 const uint32_t s0 = gpart[i >> 10] + goff[i];
-                const uint32_t area = ((hi & 0xffff) - (lo & 0xffff)) * ((hi >> 16) - (lo >> 16));
                 for (uint32_t k = 0; k < area; k++) inst_pos[s0 + k] = 0xffffffffu;
             }
         }
     }
     gsr_block_bin<true>(
-        lo, hi, bx, [&](int x, int y) { return gsr_bin_hit(hit, x, y); }, [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
+        lo, hi, bx, gsr_masked_hit(hit, mask, lo, hi), [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
         [&](uint32_t pos) { keys[pos] = key; });
 }
 
@@ -336,10 +339,10 @@ void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *
                        gpart, n_gblocks, host_hdr, host_seq);
 }
 
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
                         const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, bin_cursor, keys, hdr,
+    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, hitmask, bin_cursor, keys, hdr,
                        goff, gpart, inst_pos);
 }
 

@@ -14,6 +14,8 @@
 //   bin_offset[NB+1], wg_order[NB/4], scan_part[...]     dense exclusive offsets; work-ordered workgroup list (busy first)
 //   splats[P]      48-byte records {x,y,A,B | C,op,r,g | b,depth,binrect_lo,binrect_hi}: everything the compositing
 //                  kernels gather per instance sits in one record (1-2 cache lines per gather instead of 3 arrays)
+//   hitmask[P]     u32: bit k = the k-th cell (row-major) of the Gaussian's bin rect passed the exact ellipse/bin test, computed once
+//                  by k_preprocess and reused by k_scatter (rects of more than 32 cells store ~0 and are re-tested there)
 //   keys[cap]      u64 (depth_bits << 32 | gaussian id), binned, then sorted in LDS per bin
 //   point_list[cap] u32 sorted gaussian ids (what the compositing kernels walk)
 //   final_T[H*W], n_contrib[H*W]                         per-pixel state kept for the backward
@@ -54,7 +56,7 @@ struct __attribute__((aligned(64))) GsrGradAcc {
 static_assert(sizeof(GsrGradAcc) == 64, "grad record must be 64 bytes");
 
 struct GsrLayout {
-    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, keys, point_list, final_T, n_contrib;
+    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, hitmask, keys, point_list, final_T, n_contrib;
     size_t total_fwd;  // bytes a forward-only workspace needs
     size_t goff, gscan_part, inst_pos, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
@@ -87,6 +89,7 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
     L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 16);
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
+    L.hitmask = o;    o = gsr_align_up(o + p * 4);
     L.keys = o;       o = gsr_align_up(o + c * 8);
     L.point_list = o; o = gsr_align_up(o + c * 4);
     L.final_T = o;    o = gsr_align_up(o + npix * 4);
@@ -149,6 +152,28 @@ __device__ __forceinline__ bool gsr_bin_hit(const GsrHit &h, int bxi, int byi) {
         best = fminf(best, h.A * dx * dx + 2.f * h.B * dx * dy + h.C * dy * dy);
     }
     return best <= h.thr;
+}
+
+// Bit k of a hit mask = cell k (row-major inside the rect [x0,x1) x [y0,y1)) passed the exact test.  Rects of more than 32
+// cells are not cached: their cells are re-tested wherever the mask is consumed.
+// hit predicate backed by a cached mask (falls back to the exact test for uncached rects)
+struct GsrMaskedHit {
+    GsrHit h;
+    uint32_t mask;
+    int x0, y0, w;
+    bool big;
+    __device__ __forceinline__ bool operator()(int x, int y) const {
+        if (big) return gsr_bin_hit(h, x, y);
+        return (mask >> ((y - y0) * w + (x - x0))) & 1u;
+    }
+};
+__device__ __forceinline__ GsrMaskedHit gsr_masked_hit(const GsrHit &h, uint32_t mask, uint32_t lo, uint32_t hi) {
+    GsrMaskedHit m;
+    m.h = h; m.mask = mask;
+    m.x0 = lo & 0xffff; m.y0 = lo >> 16; m.w = (int)(hi & 0xffff) - m.x0;
+    const int area = m.w * ((int)(hi >> 16) - m.y0);
+    m.big = area > 32;
+    return m;
 }
 
 template <bool EMIT, typename Hit, typename Reserve, typename Emit>
@@ -223,10 +248,10 @@ struct GsrFwdParams {
     uint32_t *goff, *gpart;  // backward tail of the workspace (NULL for a forward-only workspace)
 };
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s);
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s);
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
                         const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, hipStream_t s);

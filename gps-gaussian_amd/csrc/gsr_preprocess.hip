@@ -88,7 +88,7 @@ __device__ __forceinline__ void cov2d(const Ewa &e, const float c6[6], float &a,
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats,
+__global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint32_t *__restrict__ hitmask,
                                                                uint32_t *__restrict__ bin_count, GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t rlo = 0, rhi = 0;
@@ -193,8 +193,20 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
         if (i < q.P) q.goff[i] = woff + x - area;  // prefix inside this block of 1024 Gaussians
         if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan_b turns these into the prefix of the blocks
     }
+    // the exact ellipse/bin test of every cell of the rect is evaluated ONCE, here; the outcomes are kept as a bit mask
+    // (cell k = row-major index inside the rect) that k_scatter reuses instead of re-testing every cell twice
+    uint32_t mask = 0u;
+    const int mx0 = rlo & 0xffff, my0 = rlo >> 16, mw = (int)(rhi & 0xffff) - mx0;
     gsr_block_bin<false>(
-        rlo, rhi, q.bx, [&](int x, int y) { return gsr_bin_hit(hit, x, y); }, [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {});
+        rlo, rhi, q.bx,
+        [&](int x, int y) {
+            const bool h = gsr_bin_hit(hit, x, y);
+            const int k = (y - my0) * mw + (x - mx0);
+            if (h && k < 32) mask |= 1u << k;
+            return h;
+        },
+        [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {});
+    if (i < q.P) hitmask[i] = mask;
 }
 
 __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrSplat *__restrict__ splats,
@@ -338,9 +350,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
 
 }  // namespace
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s) {
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess, dim3((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, p, splats, bin_count, hdr);
+    hipLaunchKernelGGL(k_preprocess, dim3((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, p, splats, hitmask, bin_count, hdr);
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
