@@ -115,7 +115,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     float *final_T = reinterpret_cast<float *>(at(workspace, L.final_T));
     uint32_t *n_contrib = reinterpret_cast<uint32_t *>(at(workspace, L.n_contrib));
 
-    // header + bin_count are adjacent: one memset
+    // header + scan partials (their ready flags) + bin_count are adjacent: one memset
     if (hipMemsetAsync(hdr, 0, L.bin_offset - L.header, s) != hipSuccess) return GPSGS_E_LAUNCH;
     if (P == 0) {  // upstream returns its zero-initialised image (NOT the background) when there is nothing to draw
         if (hipMemsetAsync(out_color, 0, sizeof(float) * 3 * (size_t)width * height, s) != hipSuccess) return GPSGS_E_LAUNCH;

@@ -67,22 +67,57 @@ __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_
     }
 }
 
-// phase B: every block re-derives its prefix from the (few) block partials, then scans its own 1024 bins
-__global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, const uint4 *__restrict__ part,
+// phase B: every block re-derives its prefix from the (few) block partials, then scans its own 1024 bins.
+// FUSED = true: phase A runs in the same launch -- every block publishes its partial with a release flag and waits for the
+// flags of all blocks (the total of ALL blocks is needed, so all blocks must be co-resident: the launcher only fuses up to
+// GSR_SCAN_FUSE_MAX blocks = 131,072 bins, a 2896^2 image; beyond that the two-launch form is used).  Saves one launch.
+#define GSR_SCAN_FUSE_MAX 128
+template <bool FUSED>
+__global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part,
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
                                                uint32_t *__restrict__ wg_order, int NB, int nblocks, int64_t cap,
                                                GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
                                                uint32_t *__restrict__ host_hdr, uint32_t host_seq) {
     __shared__ uint32_t wsum[SB / 64];
+    __shared__ uint4 sp[FUSED ? GSR_SCAN_FUSE_MAX : 1];
     const int tid = threadIdx.x;
+    const int b = blockIdx.x * SB + tid;
+    const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
+    if (FUSED) {
+        __shared__ uint32_t red[3][SB / 64];
+        const int lane = tid & 63, wid = tid >> 6;
+        uint32_t s = c, nb = c > 0 ? 1u : 0u, mx = c;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            s += __shfl_xor(s, d, 64);
+            nb += __shfl_xor(nb, d, 64);
+            const uint32_t y = __shfl_xor(mx, d, 64);
+            mx = y > mx ? y : mx;
+        }
+        if (lane == 0) { red[0][wid] = s; red[1][wid] = nb; red[2][wid] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t ts = 0, tb = 0, tm = 0;
+            for (int w = 0; w < SB / 64; w++) { ts += red[0][w]; tb += red[1][w]; tm = red[2][w] > tm ? red[2][w] : tm; }
+            uint32_t *me = reinterpret_cast<uint32_t *>(part + blockIdx.x);
+            me[0] = ts; me[1] = tb; me[2] = tm;
+            __hip_atomic_store(me + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ready flag (zeroed by the forward's memset)
+        }
+        if (tid < nblocks) {  // wait for every block's partial (all blocks are resident: nblocks <= GSR_SCAN_FUSE_MAX)
+            uint32_t *other = reinterpret_cast<uint32_t *>(part + tid);
+            while (__hip_atomic_load(other + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+            sp[tid] = make_uint4(__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(other + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1u);
+        }
+        __syncthreads();
+    }
     uint32_t pre_sum = 0, pre_busy = 0, tot_sum = 0, tot_busy = 0, tot_max = 0;
-    for (int i = 0; i < nblocks; i++) {  // wave-uniform loads of a handful of uint4
-        const uint4 p = part[i];
+    for (int i = 0; i < nblocks; i++) {  // a handful of uint4
+        const uint4 p = FUSED ? sp[i] : part[i];
         if (i < (int)blockIdx.x) { pre_sum += p.x; pre_busy += p.y; }
         tot_sum += p.x; tot_busy += p.y; tot_max = p.z > tot_max ? p.z : tot_max;
     }
-    const int b = blockIdx.x * SB + tid;
-    const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
     uint32_t blk_total;
     const uint32_t off = pre_sum + block_exscan(c, wsum, &blk_total);
     if (b < NB) {
@@ -334,8 +369,13 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s) {
     const int nblocks = (NB + SB - 1) / SB;
+    if (nblocks <= GSR_SCAN_FUSE_MAX) {
+        hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap,
+                           hdr, gpart, n_gblocks, host_hdr, host_seq);
+        return;
+    }
     hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB);
-    hipLaunchKernelGGL(k_scan_b, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr,
+    hipLaunchKernelGGL(k_scan_b<false>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr,
                        gpart, n_gblocks, host_hdr, host_seq);
 }
 

@@ -82,12 +82,12 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     size_t o = 0;
     const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.NB > 0 ? L.NB : 1), c = (size_t)(cap > 0 ? cap : 1);
     const size_t npix = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
-    L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + bin_count are zeroed by ONE memset
+    L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + scan_part + bin_count are zeroed by ONE memset
+    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 16);
     L.bin_count = o;  o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.bin_offset = o; o = gsr_align_up(o + (t + 1) * 4);
     L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
-    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 16);
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
     L.hitmask = o;    o = gsr_align_up(o + p * 4);
     L.keys = o;       o = gsr_align_up(o + c * 8);

@@ -413,3 +413,20 @@ def test_fuzz_odd_shapes_and_degenerate_clouds(cfg):
         if (~touched).any():
             assert e[~touched].max() <= GRAD_TOL, "%s: %.3e" % (k, e[~touched].max())
         assert np.abs(grads[k][oradii == 0]).max(initial=0.0) == 0.0
+
+
+def test_very_wide_image_takes_the_two_launch_scan():
+    """More than 131,072 bins (here 4096 x 2104 pixels = 134,656 bins): the fused one-launch scan (all scan blocks must be
+    co-resident) hands over to the two-launch form; results must still match the oracle."""
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_uniform_cloud(3000, 4096, 2104, seed=21, scale_med=0.02, z_range=(0.5, 4.0), behind_frac=0.02)
+    dpix = np.random.default_rng(2).standard_normal((3, 2104, 4096)).astype(np.float32)
+    img, radii, grads, _ = hip_render(g, dpix)
+    o, oimg, oradii = oracle_render(g, "f32")
+    np.testing.assert_array_equal(radii, oradii)
+    solid, touched = touched_by_fragile(o)
+    assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
+    og = o.backward(dpix)
+    for k in grads:
+        e = _norm_err(grads[k], og[k])
+        assert e[~touched].max() <= GRAD_TOL, k
