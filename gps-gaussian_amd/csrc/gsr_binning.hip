@@ -3,8 +3,8 @@
 // Upstream builds one global list of (tile<<32 | depth) keys and radix-sorts all R of them through HBM (~6 passes
 // of 24 B/instance) after a blocking D2H read of R.  Here the bin part of the key is
 // resolved by construction instead of by sorting:
-//   k_scan_a/b two-phase parallel exclusive scan of the per-bin counts (written by k_preprocess into one-counter-per-
-//              128-B-line storage) -> bin_offset, cursors, R, overflow flag; R never leaves the device.  The same pass
+//   k_scan_a/b two-phase parallel exclusive scan of the per-bin counts written by k_preprocess (normally fused into ONE launch:
+//              release flags + wait) -> bin_offset, cursors, R, overflow flag; R is published to the host from here.  The same pass
 //              emits wg_order: compositing workgroups with work first (so every CU starts on real work and the empty
 //              ones drain in the gaps), in image order within each class (keeps neighbouring bins on neighbouring CUs).
 //   k_scatter  each Gaussian drops (depth_bits<<32 | id) into its bins' segments; slots are reserved with ONE returning

@@ -9,8 +9,9 @@
 //
 // Data layout in HBM (all carved from ONE caller-owned workspace, 256-byte aligned sections):
 //   header         GsrHeader (64 B)                      R needed, overflow flag, stats
-//   bin_count[NB*32], bin_cursor[NB*32]                  u32 per bin, ONE COUNTER PER 128-BYTE LINE: device-scope atomics on
-//                                                        neighbouring bins would otherwise serialise on a shared line
+//   bin_count[NB], bin_cursor[NB]                        u32 per bin (GSR_CPAD = stride in words; with the workgroup-aggregated
+//                                                        binning a bin receives only a handful of atomics, so dense counters
+//                                                        are as fast as one-per-128-byte-line ones and the scan reads them coalesced)
 //   bin_offset[NB+1], wg_order[NB/4], scan_part[...]     dense exclusive offsets; work-ordered workgroup list (busy first)
 //   splats[P]      48-byte records {x,y,A,B | C,op,r,g | b,depth,binrect_lo,binrect_hi}: everything the compositing
 //                  kernels gather per instance sits in one record (1-2 cache lines per gather instead of 3 arrays)
@@ -36,7 +37,7 @@
 #define GSR_TILE 16 // upstream's tile edge: defines rect membership and the reported radii semantics
 #define GSR_BIN 8   // our work-item edge: one wave64 per 8x8 pixels
 #define GSR_BINS_PER_WG 1 // compositing workgroup = ONE wave64 = one bin: the dispatcher then balances CUs at wave granularity
-#define GSR_CPAD 32       // u32 stride of the padded per-bin counters / cursors (one 128-byte line each)
+#define GSR_CPAD 1       // u32 stride of the per-bin counters / cursors (32 = one 128-byte line each: measured no faster)
 #define GSR_SCAN_BLOCK 1024
 
 struct __attribute__((aligned(16))) GsrSplat {
