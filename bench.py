@@ -267,6 +267,37 @@ def main():
         cpu = {"value": round(n_cpu / dt, 3), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
                "sample": "%d fwd+bwd views of the same %dx%d / %d-Gaussian workload, oracle/gsr_oracle.c fp32 + OpenMP" % (n_cpu, W, H, P)}
 
+    # ---- second CPU row: a port of the reference's Taichi point splat (lib/TaichiRender.py:13-24; taichi itself is not installed,
+    # SURVEY.md section 8d): forward-only z-buffer splat of the same view's points, sequential like its deterministic tie rule ----
+    cpu_splat = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            import ctypes as C
+            from oracle import gsr_oracle as GO
+            GO.build()
+            aux = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libaux_oracle.so"))
+            m = g["means3D"].astype(np.float64)
+            pm = cam["full_proj_transform"].astype(np.float64).reshape(4, 4)  # row-vector convention: p_hom = [x y z 1] @ M
+            ph = np.concatenate([m, np.ones((P, 1))], 1) @ pm
+            wv = np.concatenate([m, np.ones((P, 1))], 1) @ cam["world_view_transform"].astype(np.float64).reshape(4, 4)
+            pix = np.stack([((ph[:, 0] / ph[:, 3] + 1) * W - 1) * 0.5, ((ph[:, 1] / ph[:, 3] + 1) * H - 1) * 0.5, 1.0 / (wv[:, 2] + 1e-8)], 1)
+            pts = np.ascontiguousarray(np.concatenate([pix, g["colors"]], 1)[None], dtype=np.float32)
+            mask = np.ones((1, P), np.float32)
+            depth = np.zeros((1, H, W), np.float32)
+            color = -np.ones((1, 3, H, W), np.float32)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            aux.zsplat_oracle.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
+            n_s, t0 = 0, time.perf_counter()
+            while n_s < 3 or (time.perf_counter() - t0 < 2.0 and n_s < 200):
+                depth[:] = 0; color[:] = -1
+                aux.zsplat_oracle(vp(pts), vp(mask), vp(depth), vp(color), 1, P, W); n_s += 1
+            dt = time.perf_counter() - t0
+            cpu_splat = {"value": round(n_s / dt, 2), "unit": "views/s", "cores": 1, "kind": "port",
+                         "sample": "%d forward-only z-buffer splats of the same view's %d points at %dx%d (oracle/aux_oracle.c::zsplat_oracle; "
+                                   "no blending, no gradients: not comparable work, reported because the north star names this path)" % (n_s, P, W, H)}
+        except Exception as e:  # noqa: BLE001
+            cpu_splat = {"error": repr(e)[:200]}
+
     if rank == 0:
         line = {
             "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward", "value": round(value, 2),
@@ -275,7 +306,7 @@ def main():
             "config": {"workload": "BASELINE config 2: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d (Gaussian, 8x8-bin) instances, "
                                    "HIP rasteriser forward+backward, one view per step per GPU" % (W, H, P, R),
                        "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
             "forward_only_views_per_s": round(world * args.steps / el_fwd, 2),
             "deferred_check_views_per_s": {"fwd_bwd": round(world * args.steps / el_def, 2), "fwd": round(world * args.steps / el_fwd_def, 2)},
             "stages": per_stage,
