@@ -70,8 +70,10 @@ __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_
 // phase B: every block re-derives its prefix from the (few) block partials, then scans its own 1024 bins.
 // FUSED = true: phase A runs in the same launch -- every block publishes its partial with a release flag and waits for the
 // flags of all blocks (the total of ALL blocks is needed, so all blocks must be co-resident: the launcher only fuses up to
-// GSR_SCAN_FUSE_MAX blocks = 131,072 bins, a 2896^2 image; beyond that the two-launch form is used).  Saves one launch.
-#define GSR_SCAN_FUSE_MAX 128
+// GSR_SCAN_FUSE_MAX blocks = 65,536 bins, a 2048^2 image, an eighth of the chip's 512 resident 1024-thread workgroups -- so
+// even several forwards racing on different streams cannot starve each other's scan blocks; beyond that the two-launch
+// form is used).  Saves one launch.
+#define GSR_SCAN_FUSE_MAX 64
 template <bool FUSED>
 __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part,
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,

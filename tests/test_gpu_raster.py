@@ -416,7 +416,7 @@ def test_fuzz_odd_shapes_and_degenerate_clouds(cfg):
 
 
 def test_very_wide_image_takes_the_two_launch_scan():
-    """More than 131,072 bins (here 4096 x 2104 pixels = 134,656 bins): the fused one-launch scan (all scan blocks must be
+    """More than 65,536 bins (here 4096 x 2104 pixels = 134,656 bins): the fused one-launch scan (all scan blocks must be
     co-resident) hands over to the two-launch form; results must still match the oracle."""
     from gps_gaussian_amd import synthetic as S
     g = S.make_uniform_cloud(3000, 4096, 2104, seed=21, scale_med=0.02, z_range=(0.5, 4.0), behind_frac=0.02)
