@@ -133,12 +133,11 @@ __device__ __forceinline__ GsrHit gsr_hit_setup(float x, float y, float A, float
     h.rC = 1.f / C;
     return h;
 }
-__device__ __forceinline__ bool gsr_bin_hit(const GsrHit &h, int bxi, int byi) {
+// minimum of the quadratic form over the rectangle of pixel centres [X0, X1] x [Y0, Y1] against the (inflated) threshold
+__device__ __forceinline__ bool gsr_rect_hit(const GsrHit &h, float X0, float X1, float Y0, float Y1) {
     _Pragma("clang fp contract(off)")
-    const float X0 = (float)(bxi * GSR_BIN), X1 = X0 + (float)(GSR_BIN - 1);
-    const float Y0 = (float)(byi * GSR_BIN), Y1 = Y0 + (float)(GSR_BIN - 1);
     const float cx = fminf(fmaxf(h.x, X0), X1), cy = fminf(fmaxf(h.y, Y0), Y1);
-    if (cx == h.x && cy == h.y) return true;  // centre inside the bin
+    if (cx == h.x && cy == h.y) return true;  // centre inside the rectangle
     float best = 3.0e38f;
     if (cx != h.x) {  // vertical edge x = cx faces the centre
         const float dx = cx - h.x;
@@ -153,6 +152,10 @@ __device__ __forceinline__ bool gsr_bin_hit(const GsrHit &h, int bxi, int byi) {
         best = fminf(best, h.A * dx * dx + 2.f * h.B * dx * dy + h.C * dy * dy);
     }
     return best <= h.thr;
+}
+__device__ __forceinline__ bool gsr_bin_hit(const GsrHit &h, int bxi, int byi) {
+    const float X0 = (float)(bxi * GSR_BIN), Y0 = (float)(byi * GSR_BIN);
+    return gsr_rect_hit(h, X0, X0 + (float)(GSR_BIN - 1), Y0, Y0 + (float)(GSR_BIN - 1));
 }
 
 // Bit k of a hit mask = cell k (row-major inside the rect [x0,x1) x [y0,y1)) passed the exact test.  Rects of more than 32
