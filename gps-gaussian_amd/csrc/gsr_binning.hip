@@ -320,7 +320,10 @@ __device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg,
 #pragma unroll
                 for (int r = 0; r < KPL; r++) {
                     const uint64_t a = key[r], b = other[r];
-                    const bool take = lower ? (b < a) : (b > a);
+                    // lower element of the pair keeps the minimum, upper the maximum.  Keys are unique (equal only among the +inf
+                    // padding), so "b > a" is "not (b < a)": ONE 64-bit compare whose lane mask is flipped (scalar xor) for the
+                    // upper lanes -- the select-between-two-compares form compiled to 9 VALU instructions per element
+                    const bool take = (b < a) != !lower;
                     key[r] = take ? b : a;
                 }
             }
