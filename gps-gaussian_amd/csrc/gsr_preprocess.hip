@@ -225,25 +225,30 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const uint32_t rlo = __float_as_uint(rc.z), rhi = __float_as_uint(rc.w);
         const int rw = (int)(rhi & 0xffff) - (int)(rlo & 0xffff), rh = (int)(rhi >> 16) - (int)(rlo >> 16);
         const uint32_t s0 = gpart[i >> 10] + goff[i], s1 = s0 + ((rw > 0 && rh > 0) ? (uint32_t)(rw * rh) : 0u);
-        for (uint32_t sl = s0; sl < s1; sl += 4) {  // 4 slots per step: all position loads, then all record loads, then sum in order
+        for (uint32_t sl = s0; sl < s1; sl += 4) {
+            // 4 slots per step, branch-free: every load is unconditional (clamped index / record 0 as a harmless stand-in) so that
+            // all 4 position loads and then all 12 record loads are in flight together; what does not exist is dropped by a
+            // SELECT afterwards (never a multiply: the stand-in record may hold anything).  The predicated form made the
+            // compiler wait for each record before issuing the next gather.
             uint32_t pi[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) pi[u] = (sl + u < s1) ? inst_pos[sl + u] : 0xffffffffu;
+            for (int u = 0; u < 4; u++) pi[u] = inst_pos[min(sl + u, s1 - 1u)];
             float4 a0[4], a1[4];
             float a2[4];
+            bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const bool ok = pi[u] != 0xffffffffu;
-                const float4 *r4 = reinterpret_cast<const float4 *>(inst_grad + (ok ? pi[u] : 0u));
-                a0[u] = ok ? r4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-                a1[u] = ok ? r4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                a2[u] = ok ? r4[2].x : 0.f;
+                ok[u] = (sl + u < s1) && pi[u] != 0xffffffffu;
+                const float4 *r4 = reinterpret_cast<const float4 *>(inst_grad + (ok[u] ? pi[u] : 0u));
+                a0[u] = r4[0];
+                a1[u] = r4[1];
+                a2[u] = r4[2].x;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                g0.x += a0[u].x; g0.y += a0[u].y; g0.z += a0[u].z; g0.w += a0[u].w;
-                g1.x += a1[u].x; g1.y += a1[u].y; g1.z += a1[u].z; g1.w += a1[u].w;
-                g2x += a2[u];
+            for (int u = 0; u < 4; u++) {  // fixed order: slot 0, 1, 2, 3 (adding +0 for a missing slot changes nothing)
+                g0.x += ok[u] ? a0[u].x : 0.f; g0.y += ok[u] ? a0[u].y : 0.f; g0.z += ok[u] ? a0[u].z : 0.f; g0.w += ok[u] ? a0[u].w : 0.f;
+                g1.x += ok[u] ? a1[u].x : 0.f; g1.y += ok[u] ? a1[u].y : 0.f; g1.z += ok[u] ? a1[u].z : 0.f; g1.w += ok[u] ? a1[u].w : 0.f;
+                g2x += ok[u] ? a2[u] : 0.f;
             }
         }
         const float4 g2 = make_float4(g2x, 0.f, 0.f, 0.f);
