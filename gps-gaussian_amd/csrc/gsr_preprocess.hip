@@ -98,6 +98,13 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     const float p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
     const float col[3] = {q.colors[3 * (size_t)i], q.colors[3 * (size_t)i + 1], q.colors[3 * (size_t)i + 2]};
     const float op = q.opacities[i];
+    // rotation and scale are fetched up front, together with the other inputs (one memory round trip instead of a second one
+    // behind the near-plane test; a culled Gaussian wastes 28 bytes)
+    float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
+    float s_raw[3] = {q.scales[3 * (size_t)i], q.scales[3 * (size_t)i + 1], q.scales[3 * (size_t)i + 2]};
+    // keep the compiler from sinking these loads back behind the branch
+    __asm__ volatile("" : "+v"(rot.x), "+v"(rot.y), "+v"(rot.z), "+v"(rot.w), "+v"(s_raw[0]), "+v"(s_raw[1]), "+v"(s_raw[2]));
+    const float sc[3] = {q.scale_modifier * s_raw[0], q.scale_modifier * s_raw[1], q.scale_modifier * s_raw[2]};
 
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = make_float4(0.f, op, col[0], col[1]);
     float o2x = col[2], o2y = 0.f;
@@ -115,9 +122,6 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
         const float ppx = phx * pw, ppy = phy * pw;
         const float fx = (float)q.W / (2.f * q.tanfovx), fy = (float)q.H / (2.f * q.tanfovy);
 
-        const float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
-        const float sc[3] = {q.scale_modifier * q.scales[3 * (size_t)i], q.scale_modifier * q.scales[3 * (size_t)i + 1],
-                             q.scale_modifier * q.scales[3 * (size_t)i + 2]};
         float R[3][3], c6[6];
         quat_to_R(rot.x, rot.y, rot.z, rot.w, R);
         cov3d(sc, R, c6);
@@ -218,6 +222,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
     float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
     if (q.radii[i] > 0) {
         const Cam cam = load_cam(q.view, q.proj);
+        // the per-Gaussian inputs of the chain rule are requested BEFORE the record gather, so they travel alongside it
+        float in_p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
+        float4 in_rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
+        float in_s[3] = {q.scales[3 * (size_t)i], q.scales[3 * (size_t)i + 1], q.scales[3 * (size_t)i + 2]};
+        __asm__ volatile("" : "+v"(in_p[0]), "+v"(in_p[1]), "+v"(in_p[2]), "+v"(in_rot.x), "+v"(in_rot.y), "+v"(in_rot.z), "+v"(in_rot.w),
+                         "+v"(in_s[0]), "+v"(in_s[1]), "+v"(in_s[2]));
         // gather this Gaussian's instance records in rect order: fixed summation order -> reproducible gradients
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         float g2x = 0.f;
@@ -257,10 +267,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const float dxx = g1.y, dxy = g1.z, dyy = g1.w;
         dop = g2.x;
 
-        const float p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
-        const float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
-        const float sv[3] = {q.scale_modifier * q.scales[3 * (size_t)i], q.scale_modifier * q.scales[3 * (size_t)i + 1],
-                             q.scale_modifier * q.scales[3 * (size_t)i + 2]};
+        const float p[3] = {in_p[0], in_p[1], in_p[2]};
+        const float4 rot = in_rot;
+        const float sv[3] = {q.scale_modifier * in_s[0], q.scale_modifier * in_s[1], q.scale_modifier * in_s[2]};
         float Rm[3][3], c6[6];
         quat_to_R(rot.x, rot.y, rot.z, rot.w, Rm);
         cov3d(sv, Rm, c6);
