@@ -95,6 +95,56 @@ def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, st
                         "20.6 MB of network gradients (RCCL); networks not executed" % batch}
 
 
+def graph_leg(args):
+    """Secondary measurement, run by the main bench in a CHILD process (a HIP runtime that mis-handles a capture takes the
+    process down, and the headline line must survive that): the same forward + backward step captured once into a HIP graph
+    (GPSGS_CHECK=none: launches + one memset, nothing read back) and replayed --steps times."""
+    import torch
+    import gps_gaussian_amd  # noqa: F401
+    from gps_gaussian_amd import synthetic as S
+    from gps_gaussian_amd import rasterizer as RZ
+    dev = torch.device("cuda", 0)
+    render_res = args.render_res or args.res
+    smp = S.make_stereo_sample(args.res, args.gaussians, seed=S.SEED, render_res=render_res)
+    g = S.compact_sample(smp)
+    cam = smp["novel_view"]
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):  # leaves, seed gradient, warm-up and capture all on ONE stream (no cross-stream autograd syncs)
+        t = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in names}
+        m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+        rs = RZ.GaussianRasterizationSettings(
+            image_height=render_res, image_width=render_res, tanfovx=math.tan(float(cam["FovX"]) * 0.5), tanfovy=math.tan(float(cam["FovY"]) * 0.5),
+            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=torch.from_numpy(cam["world_view_transform"]).to(dev),
+            projmatrix=torch.from_numpy(cam["full_proj_transform"]).to(dev), sh_degree=3,
+            campos=torch.from_numpy(cam["camera_center"]).to(dev), prefiltered=False, debug=False)
+        rast = RZ.GaussianRasterizer(rs)
+        gout = torch.randn(3, render_res, render_res, device=dev)
+
+        def step():
+            img, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=None, colors_precomp=t["colors"],
+                          scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+            return torch.autograd.grad(img, [t[k] for k in names] + [m2], gout)
+
+        step()  # sync mode: learns the capacity
+        os.environ["GPSGS_CHECK"] = "none"
+        step()
+        st.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            step()
+        for _ in range(5):
+            graph.replay()
+        st.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        st.synchronize()
+        dt = time.perf_counter() - t0
+    print(json.dumps({"graph_replay_views_per_s": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,7 +154,10 @@ def main():
     ap.add_argument("--render-res", type=int, default=None, help="render resolution (default = --res)")
     ap.add_argument("--gaussians", type=int, default=600_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-leg", action="store_true", help="(internal) time HIP-graph replays of the fwd+bwd step and print one JSON line")
     args = ap.parse_args()
+    if args.graph_leg:
+        return graph_leg(args)
 
     import numpy as np
     import torch
@@ -298,6 +351,19 @@ def main():
         except Exception as e:  # noqa: BLE001
             cpu_splat = {"error": repr(e)[:200]}
 
+    # ---- secondary: the same step replayed from a HIP graph (child process; see graph_leg) --------------------------------
+    graph_res = None
+    if rank == 0 and world == 1:
+        import subprocess
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-leg", "--steps", str(args.steps), "--res", str(args.res),
+                                 "--gaussians", str(args.gaussians)] + (["--render-res", str(args.render_res)] if args.render_res else []),
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+            lines = [x for x in cp.stdout.splitlines() if x.startswith("{")]
+            graph_res = json.loads(lines[-1]) if (cp.returncode == 0 and lines) else {"error": "child exited with %d" % cp.returncode}
+        except Exception as e:  # noqa: BLE001
+            graph_res = {"error": repr(e)[:200]}
+
     if rank == 0:
         line = {
             "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward", "value": round(value, 2),
@@ -311,6 +377,7 @@ def main():
             "deferred_check_views_per_s": {"fwd_bwd": round(world * args.steps / el_def, 2), "fwd": round(world * args.steps / el_fwd_def, 2)},
             "stages": per_stage,
             "stage2_path": stage2,
+            "hip_graph_replay": graph_res,
         }
         print(json.dumps(line))
     D.shutdown()

@@ -17,7 +17,10 @@ Host-side design notes (MI355X-first, not a translation of upstream's C++ glue):
     forward, while scatter / sort / compositing are still running, so the check costs no GPU idle time; on overflow it
     transparently re-runs with a larger capacity, so results are always exact.  `GPSGS_CHECK=deferred` never blocks:
     the header lands in pinned memory and is examined on the next call into this module; an overflow then raises
-    (capacity grows for later calls).
+    (capacity grows for later calls).  `GPSGS_CHECK=none` never looks at the header at all: the call sequence is then a pure
+    stream of kernel launches + one memset, which is what a HIP graph capture (torch.cuda.graph) needs; the caller owns the
+    capacity question (run the step once eagerly in sync mode first: the learnt capacity is reused), an overflowing view is
+    simply not rendered (the workspace header says so).
 """
 import ctypes as C
 import os
@@ -79,8 +82,8 @@ def _capacity_for(st, P):
 
 def _check_mode():
     m = os.environ.get("GPSGS_CHECK", "sync")
-    if m not in ("sync", "deferred"):
-        raise ValueError("GPSGS_CHECK must be 'sync' or 'deferred'")
+    if m not in ("sync", "deferred", "none"):
+        raise ValueError("GPSGS_CHECK must be 'sync', 'deferred' or 'none'")
     return m
 
 
@@ -237,8 +240,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags
         mode = _check_mode()
         st = _dev_state(dev)
+        if mode != "none" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gps_gaussian_amd: the capacity check reads a header back on the host and cannot run under graph capture; "
+                               "warm up eagerly, then capture with GPSGS_CHECK=none")
         with _device_guard(dev):
-            _drain_pending(st)
+            if mode != "none":
+                _drain_pending(st)
             cur_stream = torch.cuda.current_stream(dev)
             stream = C.c_void_p(cur_stream.cuda_stream)
             ring = _ring(dev)
@@ -270,7 +277,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),
                                      _ptr(radii), _ptr(ws), nbytes, cap, flags, stream)
                 _capi.check(rc, "gsr_forward")
-                if P == 0:
+                if P == 0 or mode == "none":
                     break
                 if mode == "deferred" and len(st["pending"]) >= ring.n - 1:
                     _drain_pending(st, block=True)  # never reuse a pinned slot that is still in flight
@@ -306,7 +313,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         g = grad_out_color.detach().to(dtype=torch.float32).contiguous()  # H3: may arrive non-contiguous
         with _device_guard(dev):
             st = _dev_state(dev)
-            _drain_pending(st, block=(_check_mode() == "deferred"))
+            if _check_mode() != "none":
+                _drain_pending(st, block=(_check_mode() == "deferred"))
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             d_m3 = torch.empty((P, 3), dtype=torch.float32, device=dev)
             d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)

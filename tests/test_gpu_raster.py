@@ -430,3 +430,61 @@ def test_very_wide_image_takes_the_two_launch_scan():
     for k in grads:
         e = _norm_err(grads[k], og[k])
         assert e[~touched].max() <= GRAD_TOL, k
+
+
+def test_forward_backward_under_hip_graph_capture(monkeypatch):
+    """GPSGS_CHECK=none: the call sequence is launches + one memset only, so a whole forward + backward step can be captured
+    into a HIP graph (torch.cuda.graph) and replayed; the replay must reproduce the eager result bit for bit, also after the
+    inputs were changed in place.  (Leaves and seed gradient live on the capturing stream: autograd otherwise makes the NULL
+    stream wait on captured events at the end of the backward, which this HIP runtime answers with a crash in
+    hipStreamEndCapture instead of an error.)"""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_scene(256, 30000)
+    dev = torch.device("cuda:0")
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    cap_stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(cap_stream):
+        t = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in names}
+        m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+        rs = RZ.GaussianRasterizationSettings(g["H"], g["W"], g["tanfovx"], g["tanfovy"], torch.from_numpy(g["bg"]).to(dev), 1.0,
+                                              torch.from_numpy(g["view"]).to(dev), torch.from_numpy(g["proj"]).to(dev), 3,
+                                              torch.from_numpy(g["campos"]).to(dev), False, False)
+        rast = RZ.GaussianRasterizer(rs)
+        gout = torch.randn(3, g["H"], g["W"], device=dev)
+
+        def step():
+            img, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"], scales=t["scales"],
+                          rotations=t["rotations"])
+            grads = torch.autograd.grad(img, [t[k] for k in names] + [m2], gout)
+            return img, grads
+
+        img_e, grads_e = step()                      # eager, sync mode: learns the capacity
+        with monkeypatch.context() as mp:            # sync mode cannot be captured and says so instead of spinning forever
+            mp.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+            with pytest.raises(RuntimeError):
+                step()
+        monkeypatch.setenv("GPSGS_CHECK", "none")
+        step()                                       # warm-up in the mode that will be captured
+        cap_stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap_stream):
+            img_g, grads_g = step()
+        graph.replay()
+        cap_stream.synchronize()
+        assert torch.equal(img_g, img_e)
+        for a, b in zip(grads_g, grads_e):
+            assert torch.equal(a, b)
+        with torch.no_grad():                        # new inputs, same graph
+            t["colors"].mul_(0.5)
+        graph.replay()
+        cap_stream.synchronize()
+        monkeypatch.setenv("GPSGS_CHECK", "sync")
+        img_e2, grads_e2 = step()
+        cap_stream.synchronize()
+        assert torch.equal(img_g, img_e2)
+        for a, b in zip(grads_g, grads_e2):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
