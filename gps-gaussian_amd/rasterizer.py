@@ -217,8 +217,12 @@ def _device_guard(dev):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, grad_arena=None):
+        # grad_arena (optional, internal to pts2render): five preallocated fp32 tensors [P,3],[P,3],[P,1],[P,3],[P,4] -- row slices
+        # of batch-wide buffers -- that the backward writes dL/d(means3D, colours, opacities, scales, rotations) into instead of
+        # fresh allocations, so that the batch's gradients arrive already concatenated (render_api._SplitRows)
         rs = raster_settings
+        ctx.grad_arena = grad_arena
         lib = _capi.lib()
         if not means3D.is_cuda:
             raise RuntimeError("gps_gaussian_amd: rasteriser inputs must live on a GPU (no CPU fallback)")
@@ -303,7 +307,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         if grad_out_color is None:  # the image did not take part in the loss
-            return (None,) * 9
+            return (None,) * 10
         rs = ctx.raster_settings
         lib = _capi.lib()
         m3, col, opa, sca, rot, view, proj, bg, radii, ws = ctx.saved_tensors
@@ -316,12 +320,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             if _check_mode() != "none":
                 _drain_pending(st, block=(_check_mode() == "deferred"))
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            d_m3 = torch.empty((P, 3), dtype=torch.float32, device=dev)
             d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)
-            d_col = torch.empty((P, 3), dtype=torch.float32, device=dev)
-            d_op = torch.empty((P, 1), dtype=torch.float32, device=dev)
-            d_sc = torch.empty((P, 3), dtype=torch.float32, device=dev)
-            d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
+            arena = ctx.grad_arena
+            if arena is not None and all(a.dtype == torch.float32 and a.is_contiguous() and a.device == dev and tuple(a.shape) == (P, c)
+                                         for a, c in zip(arena, (3, 3, 1, 3, 4))):
+                d_m3, d_col, d_op, d_sc, d_rot = arena
+            else:
+                d_m3 = torch.empty((P, 3), dtype=torch.float32, device=dev)
+                d_col = torch.empty((P, 3), dtype=torch.float32, device=dev)
+                d_op = torch.empty((P, 1), dtype=torch.float32, device=dev)
+                d_sc = torch.empty((P, 3), dtype=torch.float32, device=dev)
+                d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
             if P > 0:
                 rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                       float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
@@ -329,12 +338,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       ws.numel(), ctx.cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags, stream)
                 _capi.check(rc, "gsr_backward")
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
-        return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None
+        return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None, None
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, grad_arena=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, grad_arena)
 
 
 class GaussianRasterizer(nn.Module):
@@ -342,7 +351,8 @@ class GaussianRasterizer(nn.Module):
         super().__init__()
         self.raster_settings = raster_settings
 
-    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                grad_arena=None):
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
@@ -357,7 +367,7 @@ class GaussianRasterizer(nn.Module):
                 "gps_gaussian_amd: precomputed 3D covariances are outside the GPS-Gaussian hot path (the reference always "
                 "passes scales+rotations, gaussian_renderer/__init__.py:54-62)")
         return rasterize_gaussians(means3D, means2D, None, colors_precomp, opacities, scales, rotations, None,
-                                   self.raster_settings)
+                                   self.raster_settings, grad_arena)
 
 
 def last_stats(device=None):

@@ -17,8 +17,39 @@ def _scalar(x):
     return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
 
 
-def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color):
-    """Render one novel view.  Same arguments and return value as the reference's render(): returns image [3,H,W]."""
+class _SplitRows(torch.autograd.Function):
+    """packed[rows, C] -> row chunks, like torch.split -- but if the chunk gradients come back as the matching consecutive row
+    slices of ONE buffer (the rasteriser backward was handed such slices: grad_arena), that buffer IS the gradient of `packed`
+    and nothing is copied.  Otherwise falls back to what SplitBackward does: one concatenation."""
+
+    @staticmethod
+    def forward(ctx, packed, sizes, arena):
+        ctx.sizes = sizes
+        ctx.arena = arena
+        ctx.shape = tuple(packed.shape)
+        ctx.set_materialize_grads(False)
+        return tuple(c.view_as(c) for c in packed.detach().split(sizes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        arena = ctx.arena
+        if arena is not None:
+            off, ok = 0, True
+            for g, n in zip(grads[:-1], ctx.sizes[:-1]):  # the last chunk is the unused tail of the packed capacity
+                if n and (g is None or g.data_ptr() != arena.data_ptr() + off * arena.stride(0) * 4 or g.shape[0] != n):
+                    ok = False
+                    break
+                off += n
+            if ok:
+                return arena, None, None
+        parts = [g if g is not None else torch.zeros((n,) + ctx.shape[1:], dtype=torch.float32, device=arena.device if arena is not None else None)
+                 for g, n in zip(grads, ctx.sizes)]
+        return torch.cat(parts, dim=0), None, None
+
+
+def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color, grad_arena=None):
+    """Render one novel view.  Same arguments and return value as the reference's render(): returns image [3,H,W].
+    (grad_arena: internal, see pts2render.)"""
     nv = data['novel_view']
     bg = torch.tensor(bg_color, dtype=torch.float32, device=pts_xyz.device)
     screenspace_points = torch.zeros_like(pts_xyz, dtype=torch.float32, requires_grad=True, device=pts_xyz.device) + 0
@@ -33,7 +64,7 @@ def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color):
         sh_degree=3, campos=nv['camera_center'][idx], prefiltered=False, debug=False)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     rendered_image, _ = rasterizer(means3D=pts_xyz, means2D=screenspace_points, shs=None, colors_precomp=pts_rgb,
-                                   opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+                                   opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None, grad_arena=grad_arena)
     return rendered_image
 
 
@@ -51,10 +82,22 @@ def pts2render(data, bg_color):
     # ONE split per packed tensor (its backward is one concatenation of the per-sample gradients); B Python slices would make
     # autograd zero-fill and add a full-size gradient per sample and tensor (measured: 0.6 ms of a 4.1 ms stage-2 iteration)
     sizes = [offs[i + 1] - offs[i] for i in range(bs)] + [xyz.shape[0] - offs[bs]]
-    parts = [torch.split(t, sizes) for t in (xyz, rgb, rot, scale, opacity)]
+    packed = (xyz, rgb, rot, scale, opacity)
+    if any(t.requires_grad for t in packed):
+        # gradient arenas: one buffer per packed tensor; every sample's rasteriser backward writes its rows in place and the
+        # split's backward hands the whole buffer on (no per-sample allocation, no concatenation).  Rows behind offs[bs] are
+        # never read by the pack backward.
+        arenas = [torch.empty(t.shape, dtype=torch.float32, device=t.device) for t in packed]
+        a_parts = [a.split(sizes) for a in arenas]
+    else:
+        arenas, a_parts = [None] * 5, None
+    parts = [_SplitRows.apply(t, sizes, a) for t, a in zip(packed, arenas)]
     out = []
     for i in range(bs):
-        out.append(render(data, i, parts[0][i], parts[1][i], parts[2][i], parts[3][i], parts[4][i], bg_color=bg_color).unsqueeze(0))
+        # arena order expected by the rasteriser: means3D, colours, opacities, scales, rotations
+        ga = (a_parts[0][i], a_parts[1][i], a_parts[4][i], a_parts[3][i], a_parts[2][i]) if a_parts is not None else None
+        out.append(render(data, i, parts[0][i], parts[1][i], parts[2][i], parts[3][i], parts[4][i], bg_color=bg_color,
+                          grad_arena=ga).unsqueeze(0))
     data['novel_view']['img_pred'] = torch.cat(out, dim=0)
     return data
 
