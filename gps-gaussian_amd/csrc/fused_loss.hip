@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float *__restrict__ x1g,
         const bool in = gx < W && gy < H;
         const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
         const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
-        const float rB1 = 1.f / B1, rB2 = 1.f / B2;
+        const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);  // 1-ulp reciprocals: B1, B2 >= C1, C2 > 0
         const float smap = A1 * A2 * rB1 * rB2;
         if (in && m1) {
             const float ds_dmu1 = 2.f * mu2 * A2 * rB1 * rB2 - 2.f * mu1 * smap * rB1;
