@@ -16,6 +16,7 @@ SYMBOLS = (
 GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
 _ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "no HIP device"}
 GSR_FLAG_DEBUG = 1
+GSR_FLAG_NO_LARGE_SORT = 4
 GSR_FLAG_TIMING = 2
 STAGES = ("preprocess", "scan", "scatter", "sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 

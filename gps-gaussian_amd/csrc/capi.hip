@@ -142,7 +142,8 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCAN, s);
-        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq, s);
+        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
+                        (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
@@ -152,7 +153,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SORT, s);
-        gsr_launch_sort(L.NB, bin_offset, wg_order, keys, point_list, hdr, s);
+        gsr_launch_sort(L.NB, bin_offset, wg_order, keys, point_list, hdr, (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {

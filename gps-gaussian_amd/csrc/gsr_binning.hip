@@ -79,7 +79,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
                                                uint32_t *__restrict__ wg_order, int NB, int nblocks, int64_t cap,
                                                GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
-                                               uint32_t *__restrict__ host_hdr, uint32_t host_seq) {
+                                               uint32_t *__restrict__ host_hdr, uint32_t host_seq, int no_large_sort) {
     __shared__ uint32_t wsum[SB / 64];
     __shared__ uint4 sp[FUSED ? GSR_SCAN_FUSE_MAX : 1];
     const int tid = threadIdx.x;
@@ -152,14 +152,17 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     if (blockIdx.x == 0 && tid == 0) {
         bin_offset[NB] = tot_sum;
         hdr->num_rendered = tot_sum;
-        hdr->overflow = ((int64_t)tot_sum > cap || (int64_t)tot_slots > cap) ? 1u : 0u;
+        // a list longer than 1024 entries while the caller skipped the large-list sort launch is reported like an overflow:
+        // every later kernel exits, the caller sees max_tile_count > 1024 and calls again with that launch
+        const bool ovf_b = (int64_t)tot_sum > cap || (int64_t)tot_slots > cap || (no_large_sort && tot_max > 1024u);
+        hdr->overflow = ovf_b ? 1u : 0u;
         hdr->max_tile_count = tot_max;
         hdr->num_busy_wgs = tot_busy;
         hdr->num_slots = tot_slots;
         if (host_hdr) {
             // early notification: the header goes straight to host-coherent pinned memory from here, so the host can check
             // capacity while scatter / sort / compositing are still running (no copy engine, no event in the stream)
-            const uint32_t ovf = ((int64_t)tot_sum > cap || (int64_t)tot_slots > cap) ? 1u : 0u;
+            const uint32_t ovf = ovf_b ? 1u : 0u;
             volatile uint32_t *h = host_hdr;
             h[0] = tot_sum; h[1] = 0u; h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = 0u;
             __threadfence_system();
@@ -372,16 +375,17 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 }  // namespace
 
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
-                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s) {
+                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
+                     hipStream_t s) {
     const int nblocks = (NB + SB - 1) / SB;
     if (nblocks <= GSR_SCAN_FUSE_MAX) {
         hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap,
-                           hdr, gpart, n_gblocks, host_hdr, host_seq);
+                           hdr, gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0);
         return;
     }
     hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB);
     hipLaunchKernelGGL(k_scan_b<false>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr,
-                       gpart, n_gblocks, host_hdr, host_seq);
+                       gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0);
 }
 
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
@@ -392,8 +396,9 @@ void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *h
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
-                     const GsrHeader *hdr, hipStream_t s) {
+                     const GsrHeader *hdr, bool no_large_sort, hipStream_t s) {
     if (NB <= 0) return;
     hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    if (no_large_sort) return;  // the scan has turned any list longer than 1024 into an overflow (nothing downstream runs)
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 64 ? NB : 64), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

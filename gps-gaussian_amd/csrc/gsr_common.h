@@ -254,11 +254,12 @@ struct GsrFwdParams {
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
-                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s);
+                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
+                     hipStream_t s);
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
                         const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
-                     const GsrHeader *hdr, hipStream_t s);
+                     const GsrHeader *hdr, bool no_large_sort, hipStream_t s);
 void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
 void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,

@@ -265,6 +265,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                     # the device publishes the instance count to pinned memory right after the binning scan; the host
                     # checks capacity while scatter / sort / compositing are still running (no GPU idle time)
                     hdr, w32, hdr_ptr, seq = ring.next_notify()
+                    # the same header carries the longest bin list: as long as none has exceeded 1024 entries on this device,
+                    # the (then idle, ~5 us) large-list sort launch is left out -- a surprise is reported like an overflow
+                    skip_large = not st.get("big_bins", False)
+                    flags = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
                     rc = lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
                                                 float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
                                                 _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
@@ -273,10 +277,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _wait_notify(w32, seq, cur_stream)
                     R, overflow, need = _decode(hdr)
                     _learn(st, R, need, P)
+                    if int(w32[3]) > 768:
+                        st["big_bins"] = True  # sticky, with margin: from now on the large-list sort is always launched
                     if not overflow:
                         break
                     cap = _capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
                     continue
+                flags &= ~_capi.GSR_FLAG_NO_LARGE_SORT  # only the early-notification path can verify that shortcut
                 rc = lib.gsr_forward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),
                                      _ptr(radii), _ptr(ws), nbytes, cap, flags, stream)

@@ -51,6 +51,9 @@ enum {
 /* flags for gsr_forward / gsr_backward */
 #define GSR_FLAG_DEBUG 1u  /* synchronise and check after every kernel (the reference hard-codes debug=False) */
 #define GSR_FLAG_TIMING 2u /* bracket every stage with hipEvents on `stream`; read them with gsr_timing_read() */
+#define GSR_FLAG_NO_LARGE_SORT 4u /* the caller expects no bin list longer than 1024 entries: the (normally idle) 1024-thread sort
+                                    launch is skipped.  If a longer list does turn up, the scan reports it as an OVERFLOW (nothing is
+                                    rendered; max_tile_count > 1024 in the header tells the two cases apart): call again without it */
 #define GSR_FLAG_TIMING_STAGE(k) (GSR_FLAG_TIMING | (((unsigned)(k) + 1u) << 4)) /* ... or only stage k (GSR_STAGE_*) */
 
 /* stage ids reported by gsr_timing_read() */

@@ -488,3 +488,30 @@ def test_forward_backward_under_hip_graph_capture(monkeypatch):
         for a, b in zip(grads_g, grads_e2):
             assert torch.equal(a, b)
     torch.cuda.synchronize()
+
+
+def test_skipped_large_sort_launch_is_detected_and_repaired():
+    """Fresh device state: the first forward leaves out the large-list sort launch.  A bin with more than 1024 entries must then
+    come back as a reported overflow and be re-rendered with that launch -- exact result, and the shortcut stays off afterwards."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+
+    def _stack_scene(n, seed):
+        g = S.make_uniform_cloud(n, 32, 32, seed=seed, scale_med=0.2, z_range=(1.0, 6.0), behind_frac=0.0)
+        g["opacities"] = (g["opacities"] * 0.05).astype(np.float32)
+        return g
+
+    RZ._state.clear()
+    g = _stack_scene(24000, seed=5)   # bins of several thousand entries
+    img, _, _, _ = hip_render(g, np.ones((3, 32, 32), np.float32))
+    assert RZ._dev_state(torch.device("cuda:0")).get("big_bins") is True
+    o, oimg, _ = oracle_render(g, "f32")
+    solid, _ = touched_by_fragile(o)
+    assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
+    g2 = _stack_scene(400, seed=6)   # short lists right after: still exact
+    img2, _, _, _ = hip_render(g2, np.ones((3, 32, 32), np.float32))
+    o2, oimg2, _ = oracle_render(g2, "f32")
+    solid2, _ = touched_by_fragile(o2)
+    assert np.abs(img2 - oimg2).max(0)[solid2].max() <= RGB_TOL
+    RZ._state.clear()
