@@ -282,6 +282,73 @@ __device__ __forceinline__ void sort_one_bin(uint64_t *sk, uint32_t off, uint32_
 // per lane x ~16 LDS cycles for 512 keys).  Here every partner is `e ^ mask`, so strides below KPL are register-to-
 // register and the rest are lane-xor exchanges (ds_bpermute through the LDS crossbar, no bank access): ~4x less LDS
 // pressure and no barrier of any kind.  Lists are padded to 64*KPL with +inf keys, so every comparator is unconditional.
+// value of lane (lane ^ LM): a DPP move on the VALU where the pattern exists inside a 16-lane row (no LDS round trip: the
+// network is a chain of dependent exchanges, and a wave spent half its life waiting for ds_bpermute results), the LDS crossbar
+// otherwise.  xor 1, 2, 3 = quad permutes; 7 / 15 = half-row / row mirror; 8 = rotate by 8; 4 = two shifted moves with
+// complementary bank masks.
+template <uint32_t LM>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    const int x = (int)v;
+    if (LM == 1u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    if (LM == 2u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    if (LM == 3u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+    if (LM == 7u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    if (LM == 15u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); // row_mirror
+    if (LM == 8u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);  // row_ror:8
+    if (LM == 4u) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0, 2: lane <- lane + 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);  // row_shr:4 into banks 1, 3: lane <- lane - 4
+    }
+    return (uint32_t)__shfl_xor(x, (int)LM, 64);
+}
+
+// one stage of the ascending-only bitonic network (KB = block level, ST = stage inside it; everything a compile-time constant)
+template <int KPL, int KB, int ST>
+__device__ __forceinline__ void sort_stage(uint64_t (&key)[KPL], int lane) {
+    constexpr int LOGK = KPL == 1 ? 0 : KPL == 2 ? 1 : KPL == 4 ? 2 : KPL == 8 ? 3 : 4;
+    // ST = 0: flip (mask = 2^KB - 1); ST > 0: half-cleaner of stride 2^(KB-1-ST)
+    constexpr uint32_t mask = ST == 0 ? ((1u << KB) - 1u) : (1u << (KB - 1 - ST));
+    constexpr uint32_t top = ST == 0 ? (1u << (KB - 1)) : mask;  // the element without this bit is the lower of its pair
+    constexpr uint32_t rmask = mask & (KPL - 1), lmask = mask >> LOGK;
+    if constexpr (lmask == 0) {  // both elements live in this lane's registers
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const int r2 = r ^ (int)rmask;
+            if (r2 > r) {
+                const uint64_t a = key[r], b = key[r2];
+                const bool sw = a > b;
+                key[r] = sw ? b : a;
+                key[r2] = sw ? a : b;
+            }
+        }
+    } else {  // partner element lives in lane ^ lmask, register r ^ rmask
+        const bool lower = ((uint32_t)lane & (top >> LOGK)) == 0;
+        uint64_t other[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const uint64_t mine = key[r ^ (int)rmask];
+            const uint32_t lo = lane_xor<lmask>((uint32_t)mine);
+            const uint32_t hi = lane_xor<lmask>((uint32_t)(mine >> 32));
+            other[r] = ((uint64_t)hi << 32) | lo;
+        }
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const uint64_t a = key[r], b = other[r];
+            // lower element of the pair keeps the minimum, upper the maximum.  Keys are unique (equal only among the +inf
+            // padding), so "b > a" is "not (b < a)": ONE 64-bit compare whose lane mask is flipped (scalar xor) for the
+            // upper lanes -- the select-between-two-compares form compiled to 9 VALU instructions per element
+            const bool take = (b < a) != !lower;
+            key[r] = take ? b : a;
+        }
+    }
+}
+template <int KPL, int LOGN, int KB, int ST>
+__device__ __forceinline__ void sort_stages_from(uint64_t (&key)[KPL], int lane) {
+    sort_stage<KPL, KB, ST>(key, lane);
+    if constexpr (ST + 1 < KB) sort_stages_from<KPL, LOGN, KB, ST + 1>(key, lane);
+    else if constexpr (KB < LOGN) sort_stages_from<KPL, LOGN, KB + 1, 0>(key, lane);
+}
+
 template <int KPL>
 __device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, int lane) {
     constexpr int LOGK = KPL == 1 ? 0 : KPL == 2 ? 1 : KPL == 4 ? 2 : KPL == 8 ? 3 : 4;
@@ -292,46 +359,7 @@ __device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg,
         const uint32_t e = (uint32_t)lane * KPL + r;
         key[r] = e < n ? seg[e] : ~0ull;
     }
-#pragma unroll
-    for (int kb = 1; kb <= LOGN; kb++) {
-#pragma unroll
-        for (int st = 0; st < kb; st++) {  // st = 0: flip (mask = 2^kb - 1); st > 0: half-cleaner of stride 2^(kb-1-st)
-            const uint32_t mask = st == 0 ? ((1u << kb) - 1u) : (1u << (kb - 1 - st));
-            const uint32_t top = st == 0 ? (1u << (kb - 1)) : mask;  // the element without this bit is the lower of its pair
-            const uint32_t rmask = mask & (KPL - 1), lmask = mask >> LOGK;
-            if (lmask == 0) {  // both elements live in this lane's registers
-#pragma unroll
-                for (int r = 0; r < KPL; r++) {
-                    const int r2 = r ^ (int)rmask;
-                    if (r2 > r) {
-                        const uint64_t a = key[r], b = key[r2];
-                        const bool sw = a > b;
-                        key[r] = sw ? b : a;
-                        key[r2] = sw ? a : b;
-                    }
-                }
-            } else {  // partner element lives in lane ^ lmask, register r ^ rmask
-                const bool lower = ((uint32_t)lane & (top >> LOGK)) == 0;
-                uint64_t other[KPL];
-#pragma unroll
-                for (int r = 0; r < KPL; r++) {
-                    const uint64_t mine = key[r ^ (int)rmask];
-                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine, (int)lmask, 64);
-                    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), (int)lmask, 64);
-                    other[r] = ((uint64_t)hi << 32) | lo;
-                }
-#pragma unroll
-                for (int r = 0; r < KPL; r++) {
-                    const uint64_t a = key[r], b = other[r];
-                    // lower element of the pair keeps the minimum, upper the maximum.  Keys are unique (equal only among the +inf
-                    // padding), so "b > a" is "not (b < a)": ONE 64-bit compare whose lane mask is flipped (scalar xor) for the
-                    // upper lanes -- the select-between-two-compares form compiled to 9 VALU instructions per element
-                    const bool take = (b < a) != !lower;
-                    key[r] = take ? b : a;
-                }
-            }
-        }
-    }
+    sort_stages_from<KPL, LOGN, 1, 0>(key, lane);
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const uint32_t e = (uint32_t)lane * KPL + r;
