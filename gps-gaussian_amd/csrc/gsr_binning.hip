@@ -85,6 +85,25 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     const int tid = threadIdx.x;
     const int b = blockIdx.x * SB + tid;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
+    // block 0 also owns the per-Gaussian slot prefix (training) and the header.  Neither depends on the other blocks' bins, so the
+    // slot scan runs first -- under the wait for their partials -- and the header leaves (also towards the host) as soon as the
+    // totals are known, before this block scans its own bins.
+    uint32_t tot_slots = 0;
+    auto slot_scan = [&]() {
+        if (blockIdx.x == 0 && gpart) {  // block sums of the per-Gaussian slot counts -> exclusive prefix, in place
+            uint32_t carry = 0;
+            for (int base = 0; base < n_gblocks; base += SB) {
+                const int k = base + tid;
+                const uint32_t v = k < n_gblocks ? gpart[k] : 0u;
+                uint32_t tot;
+                const uint32_t ex = block_exscan(v, wsum, &tot);
+                if (k < n_gblocks) gpart[k] = carry + ex;
+                carry += tot;
+            }
+            tot_slots = carry;  // inst_pos needs one slot per bin-rect cell (>= R: exact culling only removes instances)
+        }
+    };
+    if (!FUSED) slot_scan();
     if (FUSED) {
         __shared__ uint32_t red[3][SB / 64];
         const int lane = tid & 63, wid = tid >> 6;
@@ -105,6 +124,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
             me[0] = ts; me[1] = tb; me[2] = tm;
             __hip_atomic_store(me + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ready flag (zeroed by the forward's memset)
         }
+        slot_scan();  // after this block's partial is out, before the others' are needed
         if (tid < nblocks) {  // wait for every block's partial (all blocks are resident: nblocks <= GSR_SCAN_FUSE_MAX)
             uint32_t *other = reinterpret_cast<uint32_t *>(part + tid);
             while (__hip_atomic_load(other + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
@@ -119,35 +139,6 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         const uint4 p = FUSED ? sp[i] : part[i];
         if (i < (int)blockIdx.x) { pre_sum += p.x; pre_busy += p.y; }
         tot_sum += p.x; tot_busy += p.y; tot_max = p.z > tot_max ? p.z : tot_max;
-    }
-    uint32_t blk_total;
-    const uint32_t off = pre_sum + block_exscan(c, wsum, &blk_total);
-    if (b < NB) {
-        bin_offset[b] = off;
-        bin_cursor[(size_t)b * GSR_CPAD] = off;
-    }
-    // work-ordered workgroup list
-    const bool is_wg_lead = b < NB;
-    const bool busy = is_wg_lead && c > 0;
-    uint32_t blk_busy;
-    const uint32_t bpos = block_exscan(busy ? 1u : 0u, wsum, &blk_busy);
-    if (is_wg_lead) {
-        const uint32_t w = (uint32_t)b / GSR_BINS_PER_WG;
-        const uint32_t nbusy_before = pre_busy + bpos;
-        wg_order[busy ? nbusy_before : tot_busy + (w - nbusy_before)] = w;
-    }
-    uint32_t tot_slots = 0;
-    if (blockIdx.x == 0 && gpart) {  // training: block sums of the per-Gaussian slot counts -> exclusive prefix, in place
-        uint32_t carry = 0;
-        for (int base = 0; base < n_gblocks; base += SB) {
-            const int k = base + tid;
-            const uint32_t v = k < n_gblocks ? gpart[k] : 0u;
-            uint32_t tot;
-            const uint32_t ex = block_exscan(v, wsum, &tot);
-            if (k < n_gblocks) gpart[k] = carry + ex;
-            carry += tot;
-        }
-        tot_slots = carry;  // inst_pos needs one slot per bin-rect cell (>= R: exact culling only removes instances)
     }
     if (blockIdx.x == 0 && tid == 0) {
         bin_offset[NB] = tot_sum;
@@ -168,6 +159,22 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
             __threadfence_system();
             __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this word
         }
+    }
+    uint32_t blk_total;
+    const uint32_t off = pre_sum + block_exscan(c, wsum, &blk_total);
+    if (b < NB) {
+        bin_offset[b] = off;
+        bin_cursor[(size_t)b * GSR_CPAD] = off;
+    }
+    // work-ordered workgroup list
+    const bool is_wg_lead = b < NB;
+    const bool busy = is_wg_lead && c > 0;
+    uint32_t blk_busy;
+    const uint32_t bpos = block_exscan(busy ? 1u : 0u, wsum, &blk_busy);
+    if (is_wg_lead) {
+        const uint32_t w = (uint32_t)b / GSR_BINS_PER_WG;
+        const uint32_t nbusy_before = pre_busy + bpos;
+        wg_order[busy ? nbusy_before : tot_busy + (w - nbusy_before)] = w;
     }
 }
 
