@@ -110,6 +110,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     uint4 *scan_part = reinterpret_cast<uint4 *>(at(workspace, L.scan_part));
     GsrSplat *splats = reinterpret_cast<GsrSplat *>(at(workspace, L.splats));
     uint32_t *hitmask = reinterpret_cast<uint32_t *>(at(workspace, L.hitmask));
+    uint32_t *wg_tab = reinterpret_cast<uint32_t *>(at(workspace, L.wg_tab));
     uint64_t *keys = reinterpret_cast<uint64_t *>(at(workspace, L.keys));
     uint32_t *point_list = reinterpret_cast<uint32_t *>(at(workspace, L.point_list));
     float *final_T = reinterpret_cast<float *>(at(workspace, L.final_T));
@@ -137,7 +138,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     int rc;
     {
         StageTimer t(flags, GSR_STAGE_PREPROCESS, s);
-        gsr_launch_preprocess(q, splats, hitmask, bin_count, hdr, s);
+        gsr_launch_preprocess(q, splats, hitmask, wg_tab, bin_count, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
@@ -148,7 +149,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, L.bx, splats, hitmask, bin_cursor, keys, hdr, q.goff, q.gpart, inst_pos_fwd, s);
+        gsr_launch_scatter(P, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_pos_fwd, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
 }
 
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
-                                                            uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
+                                                            const uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
                                                             const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
                                                             const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos) {
     if (hdr->overflow) return;
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, cons
             }
         }
     }
-    gsr_block_bin<true>(
-        lo, hi, bx, gsr_masked_hit(hit, mask, lo, hi), [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
+    gsr_block_emit(
+        wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS, lo, hi, bx, gsr_masked_hit(hit, mask, lo, hi), [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
         [&](uint32_t pos) { keys[pos] = key; });
 }
 
@@ -423,10 +423,10 @@ void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *
                        gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0);
 }
 
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
                         const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, hitmask, bin_cursor, keys, hdr,
+    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr,
                        goff, gpart, inst_pos);
 }
 

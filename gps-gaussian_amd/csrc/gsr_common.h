@@ -17,6 +17,8 @@
 //                  kernels gather per instance sits in one record (1-2 cache lines per gather instead of 3 arrays)
 //   hitmask[P]     u32: bit k = the k-th cell (row-major) of the Gaussian's bin rect passed the exact ellipse/bin test, computed once
 //                  by k_preprocess and reused by k_scatter (rects of more than 32 cells store ~0 and are re-tested there)
+//   wg_tab[P/1024][4+2048]  per binning workgroup: bin box + per-bin instance counts of its 1024 Gaussians, recorded by k_preprocess
+//                  and consumed by k_scatter (which then skips the box reduction, the table clearing and the counting loop)
 //   keys[cap]      u64 (depth_bits << 32 | gaussian id), binned, then sorted in LDS per bin
 //   point_list[cap] u32 sorted gaussian ids (what the compositing kernels walk)
 //   final_T[H*W], n_contrib[H*W]                         per-pixel state kept for the backward
@@ -39,6 +41,8 @@
 #define GSR_BINS_PER_WG 1 // compositing workgroup = ONE wave64 = one bin: the dispatcher then balances CUs at wave granularity
 #define GSR_CPAD 1       // u32 stride of the per-bin counters / cursors (32 = one 128-byte line each: measured no faster)
 #define GSR_SCAN_BLOCK 1024
+#define GSR_BIN_THREADS 1024 // Gaussians per binning workgroup (k_preprocess / k_scatter)
+#define GSR_BLOCK_TAB 2048   // bins in a binning workgroup's direct-indexed LDS table
 
 struct __attribute__((aligned(16))) GsrSplat {
     float x, y, A, B;        // pixel-space mean, conic xx, xy
@@ -57,7 +61,7 @@ struct __attribute__((aligned(64))) GsrGradAcc {
 static_assert(sizeof(GsrGradAcc) == 64, "grad record must be 64 bytes");
 
 struct GsrLayout {
-    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, hitmask, keys, point_list, final_T, n_contrib;
+    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, hitmask, wg_tab, keys, point_list, final_T, n_contrib;
     size_t total_fwd;  // bytes a forward-only workspace needs
     size_t goff, gscan_part, inst_pos, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
@@ -91,6 +95,7 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
     L.hitmask = o;    o = gsr_align_up(o + p * 4);
+    L.wg_tab = o;     o = gsr_align_up(o + ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
     L.keys = o;       o = gsr_align_up(o + c * 8);
     L.point_list = o; o = gsr_align_up(o + c * 4);
     L.final_T = o;    o = gsr_align_up(o + npix * 4);
@@ -112,8 +117,6 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
 // direct-indexed LDS table over that rectangle (ds_add, which also hands every instance its rank) and then issues ONE
 // global atomic per touched bin (reserve(bin, count) -> base).  emit(pos) is called once per instance with its slot.
 // Incoherent input (bounding rectangle > GSR_BLOCK_TAB bins) falls back to one global atomic per instance.
-#define GSR_BIN_THREADS 1024
-#define GSR_BLOCK_TAB 2048
 
 // Exact (Gaussian, bin) culling inside the bin rect.  alpha = op*exp(-q/2) >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2
 // <= 2 ln(255 op).  The bin is listed only if the MINIMUM of q over the rectangle of its pixel centres is below that
@@ -180,8 +183,12 @@ __device__ __forceinline__ GsrMaskedHit gsr_masked_hit(const GsrHit &h, uint32_t
     return m;
 }
 
+// `tab` (count pass only, may be NULL): this workgroup's table is also written to global memory as {bx0, by0, bw, bh, counts[bw*bh]}
+// (bw = -1: not recorded -- incoherent input) so that the scatter pass of the SAME 1024 Gaussians can start from it
+// (gsr_block_emit) instead of rebuilding it.
+#define GSR_WG_TAB_WORDS (4 + GSR_BLOCK_TAB)
 template <bool EMIT, typename Hit, typename Reserve, typename Emit>
-__device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, Hit hit, Reserve reserve, Emit emit) {
+__device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, Hit hit, Reserve reserve, Emit emit, uint32_t *tab = nullptr) {
     __shared__ int s_box[4];
     __shared__ uint32_t s_cnt[GSR_BLOCK_TAB];
     __shared__ uint32_t s_base[EMIT ? GSR_BLOCK_TAB : 1];
@@ -201,8 +208,12 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
     }
     __syncthreads();
     const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2] - bx0, bh = s_box[3] - by0;
-    if (s_box[2] < 0) return;  // nothing listed in this workgroup (uniform)
+    if (s_box[2] < 0) {  // nothing listed in this workgroup (uniform)
+        if (tab && tid < 4) tab[tid] = 0u;
+        return;
+    }
     const int area = bw * bh;
+    if (tab && tid < 4) tab[tid] = area > GSR_BLOCK_TAB ? 0xffffffffu : (uint32_t)(tid == 0 ? bx0 : tid == 1 ? by0 : tid == 2 ? bw : bh);
     if (area > GSR_BLOCK_TAB) {  // incoherent input: plain per-instance atomics (uniform branch)
         if (has)
             for (int y = y0; y < y1; y++)
@@ -222,6 +233,7 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
     __syncthreads();
     for (int t = tid; t < area; t += GSR_BIN_THREADS) {
         const uint32_t c = s_cnt[t];
+        if (tab) tab[4 + t] = c;
         if (c) {
             const int ty = t / bw, tx = t - ty * bw;
             const uint32_t base = reserve((by0 + ty) * bx + bx0 + tx, c);
@@ -238,6 +250,37 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
                 emit(s_base[t] + atomicAdd(&s_cnt[t], 1u));
             }
 }
+// Scatter pass from the recorded table: no bounding-box reduction, no table clearing, no counting loop -- one barrier.
+template <typename Hit, typename Reserve, typename Emit>
+__device__ __forceinline__ void gsr_block_emit(const uint32_t *tab, uint32_t lo, uint32_t hi, int bx, Hit hit, Reserve reserve, Emit emit) {
+    const int bw = (int)tab[2];
+    if (bw < 0) {  // not recorded (incoherent input): rebuild
+        gsr_block_bin<true>(lo, hi, bx, hit, reserve, emit);
+        return;
+    }
+    __shared__ uint32_t e_cnt[GSR_BLOCK_TAB];
+    __shared__ uint32_t e_base[GSR_BLOCK_TAB];
+    const int tid = threadIdx.x;
+    const int bx0 = (int)tab[0], by0 = (int)tab[1], area = bw * (int)tab[3];
+    if (area == 0) return;  // nothing listed in this workgroup (uniform)
+    for (int t = tid; t < area; t += GSR_BIN_THREADS) {
+        const uint32_t c = tab[4 + t];
+        e_cnt[t] = 0u;
+        if (c) {
+            const int ty = t / bw, tx = t - ty * bw;
+            e_base[t] = reserve((by0 + ty) * bx + bx0 + tx, c);
+        }
+    }
+    __syncthreads();
+    const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
+    if ((x1 > x0) && (y1 > y0))
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                if (!hit(x, y)) continue;
+                const int t = (y - by0) * bw + (x - bx0);
+                emit(e_base[t] + atomicAdd(&e_cnt[t], 1u));
+            }
+}
 #endif
 
 // Launchers implemented in the .hip files (host side).  All enqueue on `s` and never synchronise.
@@ -252,11 +295,12 @@ struct GsrFwdParams {
     uint32_t *goff, *gpart;  // backward tail of the workspace (NULL for a forward-only workspace)
 };
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s);
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
+                           hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
                      hipStream_t s);
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
                         const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s);

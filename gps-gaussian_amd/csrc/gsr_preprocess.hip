@@ -89,7 +89,8 @@ __device__ __forceinline__ void cov2d(const Ewa &e, const float c6[6], float &a,
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint32_t *__restrict__ hitmask,
-                                                               uint32_t *__restrict__ bin_count, GsrHeader *__restrict__ hdr) {
+                                                               uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_count,
+                                                               GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t rlo = 0, rhi = 0;
     GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
             if (h && k < 32) mask |= 1u << k;
             return h;
         },
-        [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {});
+        [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {},
+        wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS);
     if (i < q.P) hitmask[i] = mask;
 }
 
@@ -364,9 +366,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
 
 }  // namespace
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *bin_count, GsrHeader *hdr, hipStream_t s) {
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
+                           hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess, dim3((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, p, splats, hitmask, bin_count, hdr);
+    hipLaunchKernelGGL(k_preprocess, dim3((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, p, splats, hitmask, wg_tab, bin_count, hdr);
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
