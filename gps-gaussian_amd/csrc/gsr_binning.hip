@@ -8,9 +8,10 @@
 //              emits wg_order: compositing workgroups with work first (so every CU starts on real work and the empty
 //              ones drain in the gaps), in image order within each class (keeps neighbouring bins on neighbouring CUs).
 //   k_scatter  each Gaussian drops (depth_bits<<32 | id) into its bins' segments; slots are reserved with ONE returning
-//              global atomic per (workgroup, bin) after an LDS histogram (gsr_block_bin), not one per instance.
-//   k_sort_*   one WAVE per bin (lists <= 1024; larger ones get a 256- or 1024-thread workgroup) sorts its segment in LDS
-//              with an ascending-only bitonic network on the 64-bit key.  Keys are unique (id in the low word) so the result is deterministic and equals
+//              global atomic per (workgroup, bin), not one per instance; the per-workgroup bin table and the per-cell hit
+//              masks are the ones k_preprocess recorded (gsr_block_emit), nothing is recounted or re-tested.
+//   k_sort_*   one WAVE per bin sorts its segment with an ascending-only bitonic network on the 64-bit key, keys in
+//              registers, exchanges by DPP / LDS crossbar (lists <= 1024); longer lists get a 1024-thread workgroup in LDS.  Keys are unique (id in the low word) so the result is deterministic and equals
 //              upstream's stable radix order: depth ascending, ties by Gaussian index.
 //              Segments longer than the LDS capacity fall back to the same network run in global memory.
 // HBM traffic: 8 B written + 8 B read + 4 B written per instance, versus >= 144 B for the global radix sort.

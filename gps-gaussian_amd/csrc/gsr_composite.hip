@@ -11,10 +11,11 @@
 //   * per round a wave stages 64 splat records {x,y,A,B | C,op,r,g | b} -- colour included -- with one 48-byte gather
 //     per lane into its private LDS slice; the gather for round i+1 is issued BEFORE round i is consumed (registers),
 //     so HBM/L2 latency hides under the blend loop; the blend loop reads wave-uniform LDS addresses (broadcast);
-//   * lists are exact-extent culled per bin (gsr_common.h), so a wave never iterates a splat that cannot touch it;
+//   * lists are exact-extent culled per bin (gsr_common.h), so a wave never iterates a splat that cannot touch it; bins
+//     are taken from the work-ordered list in an XCD-aware order (xcd_list_pos) so that neighbouring bins share an L2;
 //   * backward: the 9 per-(pixel, splat) gradient terms are summed across the wave with a butterfly reduce-scatter
 //     (v_permlane32/16_swap + DPP, 22 instructions instead of 54, no LDS traffic), parked per staged splat in LDS by
-//     12 lanes and flushed once per round as 48-byte per-INSTANCE records with plain coalesced stores.  There is no
+//     12 lanes and flushed once per round as 64-byte (48 used) per-INSTANCE records with plain coalesced stores.  There is no
 //     global atomic in the backward at all (upstream issues 10 per (pixel, splat); float atomics run at only
 //     20-30 Mops/ms on MI355X): k_preprocess_bwd gathers each Gaussian's few instance records in a fixed order, so
 //     gradients are also bit-reproducible.
