@@ -288,11 +288,13 @@ def main():
     roofline = None
     if dom:
         achieved = per_stage[dom]["hbm_gbs"]
-        traffic = None
+        traffic, valu_instr = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # filled from the rocprofv3 --pmc passes (per launch)
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tfile)).get(dom, {})
+                traffic = pmc.get("hbm_bytes_per_launch")
+                valu_instr = pmc.get("valu_wave_instructions_per_launch")  # SQ_INSTS_VALU of the same kernel on the same workload
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -302,7 +304,12 @@ def main():
                     # 64 pixels per (Gaussian, bin) instance; ~30 lane-ops per pair forward, ~60 backward
                     "valu_lane_ops_per_launch": 64 * R * (60 if dom == "composite_bwd" else 30),
                     "valu_frac": round(64 * R * (60 if dom == "composite_bwd" else 30) / (per_stage[dom]["avg_us"] * 1e-6)
-                                       / (VALU_PEAK_TLANEOPS * 1e12), 4)}
+                                       / (VALU_PEAK_TLANEOPS * 1e12), 4),
+                    # what actually bounds it: VALU ISSUE slots.  One wave64 instruction occupies a SIMD for 4 cycles (16 lanes per
+                    # cycle); the 78.6 T lane-op/s figure above counts packed fp32 as two operations, which gfx950 does not deliver
+                    # from VALU code: measured instructions (rocprofv3 SQ_INSTS_VALU) x 4 cycles / (SIMDs x clock x t)
+                    "valu_issue_frac": (round(valu_instr * 4.0 / (1024 * 2.4e9 * per_stage[dom]["avg_us"] * 1e-6), 4)
+                                        if (valu_instr and render_res == 1024 and args.gaussians == 600_000) else None)}
 
     # ---- CPU baseline: the fp32 oracle on the host cores (rank 0, N=1 only), bounded sample ------------------------------
     cpu = None
