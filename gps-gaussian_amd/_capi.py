@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
-    "gsr_export_state", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
+    "gsr_export_state", "gsr_selftest", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
     "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
 )
@@ -18,6 +18,7 @@ _ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch faile
 GSR_FLAG_DEBUG = 1
 GSR_FLAG_NO_LARGE_SORT = 4
 GSR_FLAG_TIMING = 2
+GSR_FLAG_COMPOSITE_VALU = 8
 STAGES = ("preprocess", "scan", "scatter", "sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 
 
@@ -65,6 +66,8 @@ def lib():
     l.gsr_read_header.argtypes = [vp, C.POINTER(GsrHeader), vp]
     l.gsr_export_state.restype = i32
     l.gsr_export_state.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    l.gsr_selftest.restype = i32
+    l.gsr_selftest.argtypes = [vp, vp]
     l.gsr_timing_read.restype = i32
     l.gsr_timing_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int)]
     l.gsr_pack_scratch_bytes.restype = sz

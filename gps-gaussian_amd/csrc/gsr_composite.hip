@@ -19,58 +19,9 @@
 //     global atomic in the backward at all (upstream issues 10 per (pixel, splat); float atomics run at only
 //     20-30 Mops/ms on MI355X): k_preprocess_bwd gathers each Gaussian's few instance records in a fixed order, so
 //     gradients are also bit-reproducible.
-#include "gsr_common.h"
+#include "gsr_composite_common.h"
 
 namespace {
-
-constexpr int WAVE = 64;
-constexpr int WAVES = GSR_BINS_PER_WG;  // 4
-
-struct WaveGeom {
-    int bin, px, py, lane, wid;
-    bool inside;
-    uint32_t r0, r1;
-};
-
-// Position in the work-ordered list (busy bins first, row-major) this workgroup takes.  Workgroups are handed to the 8 XCDs
-// round-robin (workgroup w -> XCD w % 8) and every XCD has its own L2, while a Gaussian is listed in ~3 NEIGHBOURING bins:
-// taking the list in dispatch order would put neighbours on different XCDs and every XCD would fetch its own copy of the
-// shared splat records from HBM (measured: 2.2x the fetch traffic).  Instead the busy list is cut into runs of 64 consecutive
-// bins (half an image row at 1024^2) that are dealt to the XCDs in turn: neighbours along a row share one L2, and every XCD
-// still gets runs from all over the image (one contiguous eighth per XCD cut the traffic further but left the XCDs unevenly
-// loaded: +3 % time).  The map is a bijection on [0, 512 * ceil(busy / 512)); idle bins behind it keep their place.
-// (If that range does not fit the grid -- tiny images -- keep the identity.)
-__device__ __forceinline__ uint32_t xcd_list_pos(uint32_t w, uint32_t busy) {
-    const uint32_t span = ((busy + 511u) >> 9) << 9;
-    if (span > gridDim.x || w >= span) return w;
-    const uint32_t x = w & 7u, q = w >> 3;
-    return (((q >> 6) << 3) + x) * 64u + (q & 63u);
-}
-
-__device__ __forceinline__ WaveGeom wave_geom(int W, int H, int bx, const uint32_t *__restrict__ bin_offset,
-                                              const uint32_t *__restrict__ wg_order, uint32_t list_pos) {
-    WaveGeom g;
-    const int tid = threadIdx.x;
-    g.lane = tid & 63;
-    g.wid = tid >> 6;
-    const int wg = (int)wg_order[list_pos];  // work-ordered dispatch: workgroups with non-empty lists come first
-    const int wgs_per_row = bx / WAVES;
-    const int by_i = wg / wgs_per_row, bx_i = (wg - by_i * wgs_per_row) * WAVES + g.wid;
-    g.bin = by_i * bx + bx_i;
-    g.px = bx_i * GSR_BIN + (g.lane & 7);
-    g.py = by_i * GSR_BIN + (g.lane >> 3);
-    g.inside = g.px < W && g.py < H;
-    g.r0 = bin_offset[g.bin];
-    g.r1 = bin_offset[g.bin + 1];
-    return g;
-}
-
-__device__ __forceinline__ void wave_sync_lds() {
-    // same-wave LDS hand-off: the DS queue is in order per wave, this only pins the compiler's ordering
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __global__ __launch_bounds__(64 * WAVES) void k_composite_fwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                        const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,

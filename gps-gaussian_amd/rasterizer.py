@@ -80,6 +80,15 @@ def _capacity_for(st, P):
     return int(min(max(st["floor"], int(P * st["ratio"] * 2.0) + 4096), 0x7fffffff))
 
 
+def _composite_flag():
+    """GPSGS_COMPOSITE=mfma (default): compositing kernels that evaluate the exponents and the backward's wave reductions on the
+    matrix cores; GPSGS_COMPOSITE=valu: the vector-ALU-only kernels.  Same results within rounding."""
+    m = os.environ.get("GPSGS_COMPOSITE", "mfma")
+    if m not in ("mfma", "valu"):
+        raise ValueError("GPSGS_COMPOSITE must be 'mfma' or 'valu'")
+    return _capi.GSR_FLAG_COMPOSITE_VALU if m == "valu" else 0
+
+
 def _check_mode():
     m = os.environ.get("GPSGS_CHECK", "sync")
     if m not in ("sync", "deferred", "none"):
@@ -241,7 +250,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         view = _cam(rs.viewmatrix, 16, dev)
         proj = _cam(rs.projmatrix, 16, dev)
         bg = _cam(rs.bg, 3, dev)
-        flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags
+        family = _composite_flag()
+        flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | family
         mode = _check_mode()
         st = _dev_state(dev)
         if mode != "none" and torch.cuda.is_current_stream_capturing():
@@ -306,6 +316,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cap = _capacity_for(st, P)  # grown by _learn; re-run the whole (cheap) forward
         ctx.raster_settings = rs
         ctx.cap = cap
+        ctx.family = family  # the backward must repeat the forward's per-pixel decisions: same kernel family
         ctx.save_for_backward(m3, col, opa, sca, rot, view, proj, bg, radii, ws)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # otherwise autograd fills a zero int32 [P] "gradient" for radii on every backward
@@ -342,7 +353,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                       float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
                                       _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
-                                      ws.numel(), ctx.cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags, stream)
+                                      ws.numel(), ctx.cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | ctx.family, stream)
                 _capi.check(rc, "gsr_backward")
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
         return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None, None

@@ -54,6 +54,9 @@ enum {
 #define GSR_FLAG_NO_LARGE_SORT 4u /* the caller expects no bin list longer than 1024 entries: the (normally idle) 1024-thread sort
                                     launch is skipped.  If a longer list does turn up, the scan reports it as an OVERFLOW (nothing is
                                     rendered; max_tile_count > 1024 in the header tells the two cases apart): call again without it */
+#define GSR_FLAG_COMPOSITE_VALU 8u /* compositing on the vector ALUs only (gsr_composite.hip) instead of the default kernels that
+                                     evaluate the exponents and the backward's wave reductions on the matrix cores
+                                     (gsr_composite_mfma.hip).  Forward and backward of one view must agree on it. */
 #define GSR_FLAG_TIMING_STAGE(k) (GSR_FLAG_TIMING | (((unsigned)(k) + 1u) << 4)) /* ... or only stage k (GSR_STAGE_*) */
 
 /* stage ids reported by gsr_timing_read() */
@@ -124,6 +127,11 @@ int gsr_copy_header_async(const void *workspace, void *host_pinned_out, void *st
 
 /* Blocking helper for non-torch hosts: copies the header to host memory and synchronises `stream`. */
 int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream);
+
+/* Diagnostic: runs the matrix-core building blocks of the compositing kernels (exponent tiles, transposed reductions) on
+ * pseudo-random operands against plain per-lane evaluation.  out4 (device): {max exponent error / (1 + |value|), max relative
+ * error of the reduction sums, 1 if v_permlane32_swap behaves as documented else 0, 0}. */
+int gsr_selftest(float *out4_device, void *stream);
 
 /* Profiling helper (not thread safe, not for use under graph capture): synchronises, then adds up the hipEvent
  * durations recorded by calls that carried GSR_FLAG_TIMING since the last read.  ms_sum[GSR_STAGE_COUNT] receives the

@@ -19,6 +19,29 @@ RGB_TOL = 1e-4
 GRAD_TOL = 1e-3
 
 
+@pytest.fixture(params=["mfma", "valu"])
+def family(request, monkeypatch):
+    """Both compositing kernel families: matrix-core (default) and vector-ALU only."""
+    monkeypatch.setenv("GPSGS_COMPOSITE", request.param)
+    return request.param
+
+
+def test_matrix_core_selftest():
+    """The device functions the matrix-core compositing kernels are built from (exponent tiles through v_mfma_f32_32x32x2_f32 +
+    v_permlane32_swap, transposed LDS staging + v_mfma_f32_16x16x4_f32 reductions) against per-lane evaluation on the device."""
+    import ctypes as C
+    import torch
+    from gps_gaussian_amd import _capi
+    out = torch.full((4,), -1.0, device="cuda:0")
+    _capi.check(_capi.lib().gsr_selftest(C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_selftest")
+    torch.cuda.synchronize()
+    e_pow, e_red, swap_ok, _ = out.cpu().tolist()
+    print("selftest: exponent tile err %.3e, reduction err %.3e, swap %s" % (e_pow, e_red, swap_ok))
+    assert swap_ok == 1.0
+    assert 0 <= e_pow <= 4e-7, e_pow     # a few ulp of the value: exact products, the rounding of the last additions only
+    assert 0 <= e_red <= 2e-6, e_red
+
+
 def _hip_kat_render(scene):
     import torch
     from gps_gaussian_amd import rasterizer as RZ
@@ -32,7 +55,7 @@ def _hip_kat_render(scene):
 
 
 @pytest.mark.parametrize("case", kat_cases.ALL, ids=lambda c: c.__name__)
-def test_known_answers_on_gpu(case):
+def test_known_answers_on_gpu(case, family):
     case(_hip_kat_render, 2e-6)
 
 
@@ -53,7 +76,7 @@ def _norm_err(a, ref):
 
 
 @pytest.mark.parametrize("name", ["c1_256_30k", "cloud_333x277_20k", "cloud_big_splats_96x80", "hr_512_from_256"])
-def test_forward_backward_parity(name):
+def test_forward_backward_parity(name, family):
     import torch
     from gps_gaussian_amd import rasterizer as RZ
     g = _scenes()[name]()
@@ -383,7 +406,7 @@ _FUZZ = [  # (W, H, P, seed, scale_med, z_range, behind_frac)
 
 
 @pytest.mark.parametrize("cfg", _FUZZ, ids=lambda c: "%dx%d_P%d" % (c[0], c[1], c[2]))
-def test_fuzz_odd_shapes_and_degenerate_clouds(cfg):
+def test_fuzz_odd_shapes_and_degenerate_clouds(cfg, family):
     """Small random clouds on image sizes that are not multiples of the 8-pixel bin or the 16-pixel tile (down to 1x1), with
     Gaussians behind the camera, sub-pixel and screen-filling splats, exactly-zero and exactly-one opacities, duplicated depths:
     radii bit-exact, image and gradients within the north-star tolerances outside fragile pixels."""
