@@ -39,56 +39,65 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_fwd(int W, int H, int 
     float *wC = sC[g.wid];
 
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t last = 0;  // 1-based list position of the last splat that contributed (n_contrib)
-    bool done = !g.inside;
+    uint32_t last = 0;      // 1-based list position of the last splat that contributed (n_contrib), up to the previous round
+    uint32_t last_rnd = 0;  // ... 1-based slot of the last contributor inside the current round (0: none): an inline constant per select
+    // Per-lane predicates live as wave-uniform 64-bit masks in SGPRs and are combined on the scalar unit: one v_cmp per test, never a
+    // second compare for the complement; __builtin_amdgcn_inverse_ballot_w64 hands a mask back to v_cndmask for free.
+    typedef unsigned long long lanemask_t;
+    lanemask_t active = __ballot(g.inside);  // pixels inside the image that are not yet saturated
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);
 
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
     float nC = 0.f;
-    if (g.r0 + g.lane < g.r1) {  // prefetch round 0
-        const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[g.r0 + g.lane]);
+    if (r0 + g.lane < r1) {  // prefetch round 0
+        const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[r0 + g.lane]);
         nA = s[0]; nB = s[1]; nC = s[2].x;
     }
-    for (uint32_t base = g.r0; base < g.r1; base += WAVE) {
-        if (__ballot(!done) == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
-        wave_sync_lds();                     // previous round fully consumed
-        wA[g.lane] = nA; wB[g.lane] = nB; wC[g.lane] = nC;
+    for (uint32_t base = r0; base < r1; base += WAVE) {
+        if (active == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
+        wave_sync_lds();            // previous round fully consumed
+        wA[g.lane] = make_float4(nA.x, nA.y, -0.5f * GSR_LOG2E * nA.z, -GSR_LOG2E * nA.w);  // conic pre-scaled for gsr_power2
+        wB[g.lane] = make_float4(-0.5f * GSR_LOG2E * nB.x, nB.y, nB.z, nB.w);
+        wC[g.lane] = nC;
         wave_sync_lds();
         const uint32_t nk = base + WAVE + g.lane;
         nB.y = 0.f;  // a slot without a splat blends nothing (opacity 0 -> alpha 0 < 1/255; stale x, y, conic stay finite)
-        if (nk < g.r1) {  // prefetch the next round while this one is blended
+        if (nk < r1) {  // prefetch the next round while this one is blended
             const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[nk]);
             nA = s[0]; nB = s[1]; nC = s[2].x;
         }
-        const int cnt = (int)min((uint32_t)WAVE, g.r1 - base);
-        // Branch-free blend: per-lane predicates instead of `continue`s keep the scalar unit out of the loop (the
-        // branchy form spent ~0.8 SALU instructions per VALU instruction on exec-mask bookkeeping).
-        const uint32_t pos0 = base - g.r0;
-        // groups of 8 (the tail group is padded by opacity-0 slots; 4 and 16 measured slower); between groups one scalar test stops the round as soon as
-        // all 64 pixels are saturated -- on average half a round (~8 % of a body bin's list) is not walked at all
-        for (int j0 = 0; j0 < cnt; j0 += 8) {
-            if (__ballot(!done) == 0ull) break;
+        const int cnt = (int)min((uint32_t)WAVE, r1 - base);
+        // Branch-free blend in groups of 8 (the tail group is padded by opacity-0 slots; 4 and 16 measured slower); between groups one
+        // scalar test stops the round as soon as all 64 pixels are saturated -- on average half a round (~8 % of a body bin's list) is
+        // not walked at all
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int j = j0 + u;
-                const float4 a = wA[j];
-                const float4 b = wB[j];
-                const float c2 = wC[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(0.99f, b.y * __expf(power));
-                const bool valid = !done && !(power > 0.f) && !(alpha < 1.f / 255.f);
-                const float test_T = T * (1.f - alpha);
-                const bool stop = valid && (test_T < 0.0001f);
-                const bool use = valid && !stop;
-                done = done || stop;
-                const float w = use ? alpha * T : 0.f;
-                C0 += b.z * w;
-                C1 += b.w * w;
-                C2 += c2 * w;
-                T = use ? test_T : T;
-                last = use ? pos0 + (uint32_t)j + 1u : last;
+        for (int j0 = 0; j0 < WAVE; j0 += 8) {
+            if (j0 < cnt && active != 0ull) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = j0 + u;
+                    const float4 a = wA[j];
+                    const float4 b = wB[j];
+                    const float c2 = wC[j];
+                    const float dx = a.x - pxf, dy = a.y - pyf;
+                    const float power = gsr_power2(a.z, a.w, b.x, dx, dy);
+                    const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
+                    const lanemask_t valid = active & ~(__ballot(power > 0.f) | __ballot(alpha < 1.f / 255.f));
+                    const float test_T = __builtin_fmaf(-alpha, T, T);  // T (1 - alpha), one rounding
+                    const lanemask_t sat = __ballot(test_T < 0.0001f);
+                    active &= ~(valid & sat);
+                    const bool use = __builtin_amdgcn_inverse_ballot_w64(valid & ~sat);
+                    const float w = use ? alpha * T : 0.f;
+                    C0 += b.z * w;
+                    C1 += b.w * w;
+                    C2 += c2 * w;
+                    T = use ? test_T : T;
+                    last_rnd = use ? (uint32_t)(j + 1) : last_rnd;
+                }
             }
         }
+        last = last_rnd ? (base - r0) + last_rnd : last;
+        last_rnd = 0;
     }
     if (g.inside) {
         const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
@@ -214,7 +223,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
     for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
         const int cnt = (int)min((int64_t)WAVE, top + 1);
         wave_sync_lds();
-        wA[lane] = nA; wB[lane] = nB; wC[lane] = nC;
+        wA[lane] = make_float4(nA.x, nA.y, -0.5f * GSR_LOG2E * nA.z, -GSR_LOG2E * nA.w);  // conic pre-scaled for gsr_power2 (as the forward)
+        wB[lane] = make_float4(-0.5f * GSR_LOG2E * nB.x, nB.y, nB.z, nB.w);
+        wC[lane] = nC;
         const uint32_t curSlot = nSlot;
         wave_sync_lds();
         const int64_t ntop = top - WAVE;
@@ -225,11 +236,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
             const float4 a = wA[j];
             const float4 b = wB[j];
             const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float G = __expf(power);
+            const float power = gsr_power2(a.z, a.w, b.x, dx, dy);
+            const float G = __builtin_amdgcn_exp2f(power);
             const float alpha = fminf(0.99f, b.y * G);
-            const bool valid = (pos < last) && !(power > 0.f) && !(alpha < 1.f / 255.f);
-            if (!__any(valid)) continue;  // wave-uniform
+            const unsigned long long valid_m = __ballot(pos < last) & ~(__ballot(power > 0.f) | __ballot(alpha < 1.f / 255.f));
+            if (valid_m == 0ull) continue;  // wave-uniform
+            const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
             touched |= 1ull << j;
 
             // Per pair only the colour terms and six MOMENTS of s = dL/dG * G are formed: S0 = sum s, Sx = sum s dx, Sy, Sxx,
@@ -271,8 +283,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
             const float Sx = v0.w, Sy = v1.x, Sxx = v1.y, Sxy = v1.z, Syy = v1.w;
             const float S0 = (rs.x + rs.y) + (rs.z + rs.w);  // arrives as 4 row sums
             // dG/d(delta) = -G (A dx + B dy), -G (C dy + B dx);  dL/dconic = -0.5 s {dx^2, dx dy, dy^2};  dL/dop = G dL/dalpha = s / op
-            const float g_mx = ddelx_dx * (-sa.z * Sx - sa.w * Sy);
-            const float g_my = ddely_dy * (-sb.x * Sy - sa.w * Sx);
+            // the staged conic is pre-scaled: A = sa.z / (-0.5 log2 e), B = sa.w / (-log2 e), C = sb.x / (-0.5 log2 e)
+            const float kA = 2.f / GSR_LOG2E, kB = 1.f / GSR_LOG2E;
+            const float g_mx = ddelx_dx * (kA * sa.z * Sx + kB * sa.w * Sy);
+            const float g_my = ddely_dy * (kA * sb.x * Sy + kB * sa.w * Sx);
             const uint32_t p = g.r0 + (uint32_t)(top - lane);  // consecutive lanes -> consecutive records: coalesced
             float4 *dst = reinterpret_cast<float4 *>(inst_grad + p);
             dst[0] = make_float4(v0.x, v0.y, v0.z, g_mx);
@@ -290,7 +304,7 @@ void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *spla
                               const GsrHeader *hdr, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_fwd, dim3(wgs), dim3(64 * WAVES), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
+    hipLaunchKernelGGL(k_composite_fwd, dim3(wgs), dim3(64 * WAVES), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
                        final_T, n_contrib, hdr);
 }
 
@@ -300,6 +314,6 @@ void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *spla
                               GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(64 * WAVES), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
+    hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(64 * WAVES), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
                        final_T, n_contrib, goff, gpart, inst_pos, inst_grad, hdr);
 }

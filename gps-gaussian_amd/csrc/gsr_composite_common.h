@@ -48,6 +48,15 @@ __device__ __forceinline__ WaveGeom wave_geom(int W, int H, int bx, const uint32
     return g;
 }
 
+// The exponent of a (pixel, splat) pair in log2 units, from a conic that was pre-scaled when the splat was staged
+// (A2 = -0.5 log2(e) A, B2 = -log2(e) B, C2 = -0.5 log2(e) C): 6 instructions instead of 8 and v_exp_f32 directly.  Forward and backward
+// MUST evaluate this same sequence (explicit fma: no contraction choices left to the compiler) so that both take the same
+// alpha >= 1/255 decisions.
+#define GSR_LOG2E 1.44269504088896340736f
+__device__ __forceinline__ float gsr_power2(float A2, float B2, float C2, float dx, float dy) {
+    return __builtin_fmaf(B2 * dx, dy, __builtin_fmaf(C2 * dy, dy, (A2 * dx) * dx));
+}
+
 __device__ __forceinline__ void wave_sync_lds() {
     // same-wave LDS hand-off: the DS queue is in order per wave, this only pins the compiler's ordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr double GSR_LOG2E = 1.4426950408889634074;
+constexpr double GSR_LOG2E_D = 1.4426950408889634074;
 
 // hi / lo parts of {c0, cu, cv, cuu, cuv, cvv}, in log2 units (alpha = op * exp2(power2))
 struct PowCoef {
@@ -49,7 +49,7 @@ __device__ __forceinline__ void split_hi_lo(double c, float &hi, float &lo) {
 // Coefficients of one splat {x, y, conic A B C} about the bin centre (cx, cy):  dx = x - px = X - u,  dy = Y - v
 __device__ __forceinline__ PowCoef pow_coefs(float x, float y, float A, float B, float C, float cx, float cy) {
     const double X = (double)x - (double)cx, Y = (double)y - (double)cy;
-    const double a = (double)A * GSR_LOG2E, b = (double)B * GSR_LOG2E, c = (double)C * GSR_LOG2E;
+    const double a = (double)A * GSR_LOG2E_D, b = (double)B * GSR_LOG2E_D, c = (double)C * GSR_LOG2E_D;
     const double cu = a * X + b * Y, cv = b * X + c * Y;
     const double c0 = -0.5 * (X * cu + Y * cv);
     PowCoef p;
@@ -129,36 +129,65 @@ struct FwdState {
     lanemask_t active;  // pixels that are inside the image and not yet saturated
 };
 
-template <int S>
-__device__ __forceinline__ void fwd_half(FwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wCol, int cnt) {
+// One k-step of the exponent-tile PRODUCTION for a later half round: step M = 0..11 runs through the two pixel-half tiles (6 k-steps
+// each) of one splat half.  The production is spread over the blend of the half round before it (three steps per group of 8
+// splats), so that every wave's instruction stream is an even mix of VALU and MFMA work: with all waves of a SIMD running the
+// same code in near lockstep, long MFMA-only phases would make them queue on the matrix pipe together and then on the VALU
+// together (measured: no overlap at all), whereas evenly mixed streams overlap whatever their relative phase.
+template <int M>
+__device__ __forceinline__ void pow_step(const float (&a)[6], const PowMono &mono, f32x16 &n0, f32x16 &n1) {
+    constexpr int h = M / 6, t = M % 6;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 &acc = h ? n1 : n0;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], mono.b[h][t % 3], t == 0 ? zero : acc, 0, 0, 0);
+}
+
+template <int S, int Q>
+__device__ __forceinline__ void fwd_group(FwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wCol, int cnt,
+                                          const float (&pa)[6], const PowMono &mono, f32x16 &n0, f32x16 &n1) {
+    constexpr int j0 = 32 * S + 8 * Q;
+    // groups of 8; between groups one scalar test stops the round as soon as all 64 pixels are saturated
+    if (j0 < cnt && st.active != 0ull) {
+        float p[8];
+        pow_group(d0, d1, Q, p);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int j0 = 32 * S + 8 * q;
-        // groups of 8; between groups one scalar test stops the round as soon as all 64 pixels are saturated
-        if (j0 < cnt && st.active != 0ull) {
-            float p[8];
-            pow_group(d0, d1, q, p);
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int j = j0 + e;
-                const float4 c = wCol[j];  // {opacity, r, g, b}: wave-uniform address (LDS broadcast)
-                const float alpha = fminf(0.99f, c.x * __builtin_amdgcn_exp2f(p[e]));
-                const lanemask_t skip = __ballot(p[e] > 0.f) | __ballot(alpha < 1.f / 255.f);
-                const lanemask_t valid = st.active & ~skip;
-                const float test_T = __builtin_fmaf(-alpha, st.T, st.T);  // T (1 - alpha)
-                const lanemask_t sat = __ballot(test_T < 0.0001f);
-                const lanemask_t use_m = valid & ~sat;
-                st.active &= ~(valid & sat);
-                const bool use = __builtin_amdgcn_inverse_ballot_w64(use_m);
-                const float w = use ? alpha * st.T : 0.f;
-                st.C0 += c.y * w;
-                st.C1 += c.z * w;
-                st.C2 += c.w * w;
-                st.T = use ? test_T : st.T;
-                st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
-            }
+        for (int e = 0; e < 8; e++) {
+            const int j = j0 + e;
+            const float4 c = wCol[j];  // {opacity, r, g, b}: wave-uniform address (LDS broadcast)
+            // upstream skips power > 0, which its own (PSD) quadratic form never produces; the split evaluation here can land a few
+            // 1e-7 above zero where the true exponent is 0 (splat centre on a pixel centre): clamp instead of skipping
+            const float alpha = fminf(0.99f, c.x * __builtin_amdgcn_exp2f(fminf(p[e], 0.f)));
+            const lanemask_t valid = st.active & ~__ballot(alpha < 1.f / 255.f);
+            const float test_T = __builtin_fmaf(-alpha, st.T, st.T);  // T (1 - alpha)
+            const lanemask_t sat = __ballot(test_T < 0.0001f);
+            const lanemask_t use_m = valid & ~sat;
+            st.active &= ~(valid & sat);
+            const bool use = __builtin_amdgcn_inverse_ballot_w64(use_m);
+            const float w = use ? alpha * st.T : 0.f;
+            st.C0 += c.y * w;
+            st.C1 += c.z * w;
+            st.C2 += c.w * w;
+            st.T = use ? test_T : st.T;
+            st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
+            if (e == 1) pow_step<3 * Q>(pa, mono, n0, n1);
+            if (e == 4) pow_step<3 * Q + 1>(pa, mono, n0, n1);
+            if (e == 7) pow_step<3 * Q + 2>(pa, mono, n0, n1);
         }
+    } else {
+        pow_step<3 * Q>(pa, mono, n0, n1);
+        pow_step<3 * Q + 1>(pa, mono, n0, n1);
+        pow_step<3 * Q + 2>(pa, mono, n0, n1);
     }
+}
+
+// blend the 32 staged splats of half S from their exponent tiles (d0, d1) while producing the tiles (n0, n1) of the NEXT half from pa
+template <int S>
+__device__ __forceinline__ void fwd_half(FwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wCol, int cnt,
+                                         const float (&pa)[6], const PowMono &mono, f32x16 &n0, f32x16 &n1) {
+    fwd_group<S, 0>(st, d0, d1, wCol, cnt, pa, mono, n0, n1);
+    fwd_group<S, 1>(st, d0, d1, wCol, cnt, pa, mono, n0, n1);
+    fwd_group<S, 2>(st, d0, d1, wCol, cnt, pa, mono, n0, n1);
+    fwd_group<S, 3>(st, d0, d1, wCol, cnt, pa, mono, n0, n1);
 }
 
 __global__ __launch_bounds__(64, 4) void k_composite_fwd_mfma(int W, int H, int bx, const GsrSplat *__restrict__ splats,
@@ -166,7 +195,7 @@ __global__ __launch_bounds__(64, 4) void k_composite_fwd_mfma(int W, int H, int 
                                                            const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                            float *__restrict__ out_color, float *__restrict__ final_T,
                                                            uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr) {
-    __shared__ float4 sCol[WAVE];  // {opacity, r, g, b} of the 64 staged splats
+    __shared__ float4 sCol[2][WAVE];  // {opacity, r, g, b} of the 64 staged splats, double buffered (round parity)
     if (hdr->overflow) return;
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
@@ -181,32 +210,55 @@ __global__ __launch_bounds__(64, 4) void k_composite_fwd_mfma(int W, int H, int 
     st.last = 0; st.last_rnd = 0;
     st.active = __ballot(g.inside);
 
+    // Software pipeline over half rounds (32 staged splats): while half (r, S) is blended, the exponent tiles of the half after it
+    // are produced on the matrix pipe; the records of round r + 1 are gathered during round r's first half, turned into
+    // coefficients between the halves, and the gather of round r + 2 starts there.
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
     float nC = 0.f;
-    if (g.r0 + lane < g.r1) {  // prefetch round 0
-        const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[g.r0 + lane]);
-        nA = s[0]; nB = s[1]; nC = s[2].x;
-    }
-    for (uint32_t base = g.r0; base < g.r1; base += WAVE) {
-        if (st.active == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
-        const PowOperands op = pow_operands(pow_coefs(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy));
-        wave_sync_lds();  // previous round fully consumed
-        sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
-        wave_sync_lds();
-        const uint32_t nk = base + WAVE + lane;
+    // two-stage gather: the list entry (Gaussian id) of a slot is fetched one round before its 48-byte record, so that neither of the
+    // two dependent loads ever has less than a whole round to arrive (under load a scattered gather takes microseconds)
+    uint32_t nId = 0xffffffffu;
+    auto load_id = [&](uint32_t k) { nId = k < g.r1 ? point_list[k] : 0xffffffffu; };
+    auto load_rec = [&]() {
         nB.y = 0.f;  // a slot without a splat blends nothing (opacity 0 -> alpha 0 < 1/255; stale x, y, conic stay finite)
-        if (nk < g.r1) {  // prefetch the next round while this one is blended
-            const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[nk]);
+        if (nId != 0xffffffffu) {
+            const float4 *s = reinterpret_cast<const float4 *>(splats + nId);
             nA = s[0]; nB = s[1]; nC = s[2].x;
         }
+    };
+    load_id(g.r0 + lane);
+    load_rec();                      // round 0
+    load_id(g.r0 + WAVE + lane);
+    float opS1[6];
+    f32x16 tA0, tA1, tB0, tB1;
+    {
+        const PowOperands op = pow_operands(pow_coefs(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy));
+        sCol[0][lane] = make_float4(nB.y, nB.z, nB.w, nC);
+        load_rec();                  // round 1
+        load_id(g.r0 + 2 * WAVE + lane);
+        tA0 = pow_tile(op.a[0], mono.b[0]);
+        tA1 = pow_tile(op.a[0], mono.b[1]);
+#pragma unroll
+        for (int t = 0; t < 6; t++) opS1[t] = op.a[1][t];
+    }
+    wave_sync_lds();
+    uint32_t par = 0;
+    for (uint32_t base = g.r0; base < g.r1; base += WAVE, par ^= 1u) {
+        if (st.active == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
         const int cnt = (int)min((uint32_t)WAVE, g.r1 - base);
-        const uint32_t pos0 = base - g.r0;
-        // exponent tiles of all 64 staged splats: the tiles of the second half run on the matrix pipe while the first half is blended
-        const f32x16 d00 = pow_tile(op.a[0], mono.b[0]), d01 = pow_tile(op.a[0], mono.b[1]);
-        const f32x16 d10 = pow_tile(op.a[1], mono.b[0]), d11 = pow_tile(op.a[1], mono.b[1]);
-        fwd_half<0>(st, d00, d01, sCol, cnt);
-        fwd_half<1>(st, d10, d11, sCol, cnt);
-        st.last = st.last_rnd ? pos0 + st.last_rnd : st.last;
+        const float4 *wCol = sCol[par];
+        fwd_half<0>(st, tA0, tA1, wCol, cnt, opS1, mono, tB0, tB1);
+        // between the halves: round r + 1's records have arrived
+        const PowOperands op = pow_operands(pow_coefs(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy));
+        wave_sync_lds();
+        sCol[par ^ 1u][lane] = make_float4(nB.y, nB.z, nB.w, nC);  // the other buffer: last read in the previous round
+        wave_sync_lds();
+        load_rec();                        // records of round r + 2 (their ids were requested a round ago)
+        load_id(base + 3 * WAVE + lane);   // ids of round r + 3
+        fwd_half<1>(st, tB0, tB1, wCol, cnt, op.a[0], mono, tA0, tA1);
+#pragma unroll
+        for (int t = 0; t < 6; t++) opS1[t] = op.a[1][t];
+        st.last = st.last_rnd ? (base - g.r0) + st.last_rnd : st.last;
         st.last_rnd = 0;
     }
     if (g.inside) {
@@ -245,16 +297,29 @@ __device__ __forceinline__ RedOperand red_operand(const float *__restrict__ sD /
     return o;
 }
 // D[row = 4 (l >> 4) + r][column = l & 15] = sum over the 64 pixels of A[row][pixel] * X[column][pixel]
-__device__ __forceinline__ f32x4 red_group(const RedOperand &A, const float *__restrict__ sX, int lane) {
+struct RedB {
+    float v[16];
+};
+__device__ __forceinline__ RedB red_fetch(const float *__restrict__ sX, int lane) {
     const float4 *src = reinterpret_cast<const float4 *>(sX + (lane >> 4) * XT_KSTRIDE + (lane & 15) * XT_CSTRIDE);
     const float4 b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
-    const float bv[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-    f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;  // two accumulators: back-to-back MFMAs on one accumulator wait 40 instead of 32 cycles
-#pragma unroll
-    for (int t = 0; t < 16; t += 2) {
-        da = __builtin_amdgcn_mfma_f32_16x16x4f32(A.a[t], bv[t], da, 0, 0, 0);
-        db = __builtin_amdgcn_mfma_f32_16x16x4f32(A.a[t + 1], bv[t + 1], db, 0, 0, 0);
-    }
+    RedB r = {{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w}};
+    return r;
+}
+// k-step TT of the 16: two accumulators (even / odd steps), because back-to-back MFMAs on one accumulator wait 40 instead of 32 cycles
+template <int TT>
+__device__ __forceinline__ void red_step(const RedOperand &A, const RedB &B, f32x4 &da, f32x4 &db) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 &acc = (TT & 1) ? db : da;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A.a[TT], B.v[TT], TT < 2 ? zero : acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 red_group(const RedOperand &A, const float *__restrict__ sX, int lane) {
+    const RedB B = red_fetch(sX, lane);
+    f32x4 da, db;
+    red_step<0>(A, B, da, db); red_step<1>(A, B, da, db); red_step<2>(A, B, da, db); red_step<3>(A, B, da, db);
+    red_step<4>(A, B, da, db); red_step<5>(A, B, da, db); red_step<6>(A, B, da, db); red_step<7>(A, B, da, db);
+    red_step<8>(A, B, da, db); red_step<9>(A, B, da, db); red_step<10>(A, B, da, db); red_step<11>(A, B, da, db);
+    red_step<12>(A, B, da, db); red_step<13>(A, B, da, db); red_step<14>(A, B, da, db); red_step<15>(A, B, da, db);
     return da + db;
 }
 // Park the sums of the group's 8 splats as 12-float rows {dr, dg, db, m0 | mu, mv, muu, muv | mvv, -, -, -} of sAcc[splat]:
@@ -271,14 +336,76 @@ __device__ __forceinline__ void red_park(const f32x4 &d, float *__restrict__ acc
     if (lane >= 40 && lane < 48) row[8] = d[0];
 }
 
-__global__ __launch_bounds__(64, 3) void k_composite_bwd_mfma(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+struct BwdState {
+    float T, A;                    // transmittance in front of the current splat; (colour accumulated behind it) . dL/dpixel
+    unsigned long long touched;    // which staged splats of the round received any gradient (wave-uniform)
+    int pend;                      // group of 8 whose {w, s} columns sit in sX waiting for their reduction (-1: none), wave-uniform
+};
+
+// Group GQ (8 staged splats) of a round: blend back to front and store {w, s} transposed into sX, while the matrix pipe (a) reduces
+// the columns the PREVIOUS group left in sX (16 k-steps, two per splat; its operand fetch is issued first, ahead of this group's
+// stores: the DS queue of a wave is in order) and (b) produces the exponent tiles of the next half round (3 k-steps).
+template <int GQ>
+__device__ __forceinline__ void bwd_group(BwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wCol, float *__restrict__ sX,
+                                          float *__restrict__ accF, const RedOperand &RA, int lane, int xw, uint32_t topu, uint32_t last,
+                                          float d_r, float d_g, float d_b, float nTb, const float (&pa)[6], const PowMono &mono, f32x16 &n0,
+                                          f32x16 &n1) {
+    constexpr int Q = GQ & 3;
+    wave_sync_lds();
+    const RedB B = red_fetch(sX, lane);
+    wave_sync_lds();
+    f32x4 da, db;
+    float p[8];
+    pow_group(d0, d1, Q, p);
+    unsigned gt = 0u;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int j = 8 * GQ + e;
+        const float4 c = wCol[j];
+        const float G = __builtin_amdgcn_exp2f(fminf(p[e], 0.f));  // clamp as in the forward
+        const float alpha = fminf(0.99f, c.x * G);
+        // staged slot j sits at list position top - j (slots behind the front of the list carry opacity 0: alpha < 1/255)
+        const lanemask_t valid_m = __ballot(last > topu - (uint32_t)j) & ~__ballot(alpha < 1.f / 255.f);
+        gt |= (valid_m != 0ull) ? (1u << e) : 0u;  // scalar
+        const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+        // Branch-free: a lane this splat does not reach runs the same arithmetic with alpha = 0 and G = 0 (exact no-op), and
+        // so does a whole splat nobody reaches (7 % of the walked entries; skipping them individually would put a branch
+        // between every two splats and keep the scheduler from fetching the next splat's colour ahead of time).
+        // The colour seen behind the splat is carried as its dot product with dL/dpixel: A <- alpha cd + (1 - alpha) A.
+        const float Ge = valid ? G : 0.f;
+        const float ae = valid ? alpha : 0.f;
+        const float om = 1.f - ae;
+        const float rcp = __builtin_amdgcn_rcpf(om);
+        st.T = st.T * rcp;
+        const float cd = c.y * d_r + c.z * d_g + c.w * d_b;
+        const float w = ae * st.T;  // dchannel/dcolour
+        const float dL_dalpha = (cd - st.A) * st.T + nTb * rcp;
+        st.A = ae * cd + om * st.A;
+        const float s = (c.x * dL_dalpha) * Ge;  // s = dL/dG * G, dL/dG = opacity * dL/dalpha straight through the 0.99 clamp
+        sX[xw + XT_CSTRIDE * e] = w;
+        sX[xw + XT_CSTRIDE * (8 + e)] = s;
+        if (e == 0) { red_step<0>(RA, B, da, db); red_step<1>(RA, B, da, db); }
+        if (e == 1) { red_step<2>(RA, B, da, db); red_step<3>(RA, B, da, db); pow_step<3 * Q>(pa, mono, n0, n1); }
+        if (e == 2) { red_step<4>(RA, B, da, db); red_step<5>(RA, B, da, db); }
+        if (e == 3) { red_step<6>(RA, B, da, db); red_step<7>(RA, B, da, db); }
+        if (e == 4) { red_step<8>(RA, B, da, db); red_step<9>(RA, B, da, db); pow_step<3 * Q + 1>(pa, mono, n0, n1); }
+        if (e == 5) { red_step<10>(RA, B, da, db); red_step<11>(RA, B, da, db); }
+        if (e == 6) { red_step<12>(RA, B, da, db); red_step<13>(RA, B, da, db); }
+        if (e == 7) { red_step<14>(RA, B, da, db); red_step<15>(RA, B, da, db); pow_step<3 * Q + 2>(pa, mono, n0, n1); }
+    }
+    if (st.pend >= 0) red_park(da + db, accF + 12 * 8 * st.pend, lane);
+    st.touched |= (unsigned long long)gt << (8 * GQ);
+    st.pend = gt ? GQ : -1;
+}
+
+__global__ __launch_bounds__(64, 2) void k_composite_bwd_mfma(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                            const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                            const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                            const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
                                                            const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
                                                            const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos,
                                                            GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
-    __shared__ float4 sCol[WAVE];       // {opacity, r, g, b} of the 64 staged splats
+    __shared__ float4 sCol[2][WAVE];    // {opacity, r, g, b} of the 64 staged splats, double buffered (round parity)
     __shared__ float4 sAcc[WAVE * 3];   // per staged splat: the nine sums (12 floats)
     __shared__ __attribute__((aligned(16))) float sX[XT_WORDS];
     __shared__ __attribute__((aligned(16))) float sD[3 * WAVE];
@@ -318,83 +445,83 @@ __global__ __launch_bounds__(64, 3) void k_composite_bwd_mfma(int W, int H, int 
     const PowMono mono = pow_mono(lane);
     const int xw = (lane >> 4) * XT_KSTRIDE + (lane & 15);  // where this lane (= pixel) stores into a column of sX
 
-    float T = T_final, A = 0.f;  // A = (colour accumulated behind the current splat) . dL/dpixel
+    BwdState st;
+    st.T = T_final; st.A = 0.f; st.touched = 0ull; st.pend = -1;
     const float nTb = -T_final * bg_dot;
 
-    // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64
+    // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64.  Software pipeline as in the
+    // forward: while a half round is blended, the exponent tiles of the next one are produced; the records of the next round are
+    // gathered during the first half and turned into coefficients between the halves.
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
     float nC = 0.f;
     uint32_t nSlot = 0;  // where this lane's staged instance lives in its Gaussian's inst_pos slots
     const int bin_x = g.bin % bx, bin_y = g.bin / bx;
-    auto stage = [&](uint32_t lp) {
-        const uint32_t id = point_list[lp];
-        const float4 *s = reinterpret_cast<const float4 *>(splats + id);
-        nA = s[0]; nB = s[1];
-        const float4 c = s[2];
-        nC = c.x;
-        const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
-        const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-        nSlot = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
-    };
-    if ((int64_t)lane <= max_last - 1) stage(g.r0 + (uint32_t)(max_last - 1 - lane));
-    for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
-        const int cnt = (int)min((int64_t)WAVE, top + 1);
-        // this round's records stay in registers for the flush; a slot without a splat blends nothing (opacity 0)
-        const float sx = nA.x, sy = nA.y, sA_ = nA.z, sB_ = nA.w, sC_ = nB.x, sop = (lane < cnt) ? nB.y : 0.f;
-        const uint32_t curSlot = nSlot;
-        const PowOperands op = pow_operands(pow_coefs(sx, sy, sA_, sB_, sC_, cx, cy));
-        wave_sync_lds();  // previous round's sCol / sAcc fully consumed
-        sCol[lane] = make_float4(sop, nB.z, nB.w, nC);
-        wave_sync_lds();
-        const int64_t ntop = top - WAVE;
-        if (ntop - lane >= 0) stage(g.r0 + (uint32_t)(ntop - lane));  // prefetch the next round
-        f32x16 dt[2][2];
-        dt[0][0] = pow_tile(op.a[0], mono.b[0]); dt[0][1] = pow_tile(op.a[0], mono.b[1]);
-        dt[1][0] = pow_tile(op.a[1], mono.b[0]); dt[1][1] = pow_tile(op.a[1], mono.b[1]);
-        unsigned long long touched = 0ull;  // which staged splats received any gradient (wave-uniform)
-        const uint32_t topu = (uint32_t)top;  // slot j beyond the front of the list: topu - j wraps to a huge position, never < last
-#pragma unroll
-        for (int gq = 0; gq < 8; gq++) {  // groups of 8 staged splats = one reduction on the matrix pipe
-            if (8 * gq < cnt) {
-                float p[8];
-                pow_group(dt[gq >> 2][0], dt[gq >> 2][1], gq & 3, p);
-                unsigned gt = 0u;
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int j = 8 * gq + e;
-                    const float4 c = sCol[j];
-                    const float G = __builtin_amdgcn_exp2f(p[e]);
-                    const float alpha = fminf(0.99f, c.x * G);
-                    // staged slot j sits at list position top - j (slots behind the front of the list carry opacity 0: alpha < 1/255)
-                    const lanemask_t valid_m = __ballot(last > topu - (uint32_t)j) & ~(__ballot(p[e] > 0.f) | __ballot(alpha < 1.f / 255.f));
-                    gt |= (valid_m != 0ull) ? (1u << e) : 0u;  // scalar
-                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
-                    // Branch-free: a lane this splat does not reach runs the same arithmetic with alpha = 0 and G = 0 (exact no-op), and
-                    // so does a whole splat nobody reaches (7 % of the walked entries; skipping them individually would put a branch
-                    // between every two splats and keep the scheduler from fetching the next splat's colour ahead of time).
-                    // The colour seen behind the splat is carried as its dot product with dL/dpixel: A <- alpha cd + (1 - alpha) A.
-                    const float Ge = valid ? G : 0.f;
-                    const float ae = valid ? alpha : 0.f;
-                    const float om = 1.f - ae;
-                    const float rcp = __builtin_amdgcn_rcpf(om);
-                    T = T * rcp;
-                    const float cd = c.y * d0 + c.z * d1 + c.w * d2;
-                    const float w = ae * T;  // dchannel/dcolour
-                    const float dL_dalpha = (cd - A) * T + nTb * rcp;
-                    A = ae * cd + om * A;
-                    const float s = (c.x * dL_dalpha) * Ge;  // s = dL/dG * G, dL/dG = opacity * dL/dalpha straight through the 0.99 clamp
-                    sX[xw + XT_CSTRIDE * e] = w;
-                    sX[xw + XT_CSTRIDE * (8 + e)] = s;
-                }
-                if (gt) {
-                    touched |= (unsigned long long)gt << (8 * gq);
-                    wave_sync_lds();
-                    const f32x4 d = red_group(RA, sX, lane);
-                    red_park(d, accF + 12 * 8 * gq, lane);
-                    wave_sync_lds();  // the next group's stores must stay behind this group's operand fetch
-                }
-            }
+    // two-stage gather as in the forward: list entry one round ahead of the record
+    uint32_t nId = 0xffffffffu;
+    auto load_id = [&](int64_t pos) { nId = pos >= 0 ? point_list[g.r0 + (uint32_t)pos] : 0xffffffffu; };  // pos < 0: beyond the front of the list
+    auto load_rec = [&]() {
+        nB.y = 0.f;  // a slot without a splat blends nothing (opacity 0)
+        if (nId != 0xffffffffu) {
+            const uint32_t id = nId;
+            const float4 *sp = reinterpret_cast<const float4 *>(splats + id);
+            nA = sp[0]; nB = sp[1];
+            const float4 c = sp[2];
+            nC = c.x;
+            const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
+            const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
+            nSlot = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
         }
+    };
+    load_id(max_last - 1 - lane);
+    load_rec();
+    load_id(max_last - 1 - WAVE - lane);
+    // records of the round being blended stay in registers for its flush
+    float sx = nA.x, sy = nA.y, sA_ = nA.z, sB_ = nA.w, sC_ = nB.x, sop = nB.y;
+    uint32_t curSlot = nSlot;
+    float opS1[6];
+    f32x16 tA0, tA1, tB0, tB1;
+    {
+        const PowOperands op = pow_operands(pow_coefs(sx, sy, sA_, sB_, sC_, cx, cy));
+        sCol[0][lane] = make_float4(sop, nB.z, nB.w, nC);
+        load_rec();
+        load_id(max_last - 1 - 2 * WAVE - lane);
+        tA0 = pow_tile(op.a[0], mono.b[0]);
+        tA1 = pow_tile(op.a[0], mono.b[1]);
+#pragma unroll
+        for (int t = 0; t < 6; t++) opS1[t] = op.a[1][t];
+    }
+    wave_sync_lds();
+    uint32_t par = 0;
+    for (int64_t top = max_last - 1; top >= 0; top -= WAVE, par ^= 1u) {
+        const int cnt = (int)min((int64_t)WAVE, top + 1);
+        const uint32_t topu = (uint32_t)top;  // slot j beyond the front of the list: topu - j wraps to a huge position, never < last
+        const float4 *wCol = sCol[par];
+        st.touched = 0ull;
+        if (0 < cnt) bwd_group<0>(st, tA0, tA1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, opS1, mono, tB0, tB1);
+        if (8 < cnt) bwd_group<1>(st, tA0, tA1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, opS1, mono, tB0, tB1);
+        if (16 < cnt) bwd_group<2>(st, tA0, tA1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, opS1, mono, tB0, tB1);
+        if (24 < cnt) bwd_group<3>(st, tA0, tA1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, opS1, mono, tB0, tB1);
+        // between the halves: the next round's records have arrived (only a full round has a successor: cnt < 64 is the front of the list)
+        const float nx = nA.x, ny = nA.y, nAa = nA.z, nAb = nA.w, nCc = nB.x, nop = nB.y;
+        const uint32_t nSl = nSlot;
+        const PowOperands op = pow_operands(pow_coefs(nx, ny, nAa, nAb, nCc, cx, cy));
+        wave_sync_lds();
+        sCol[par ^ 1u][lane] = make_float4(nop, nB.z, nB.w, nC);  // the other buffer: last read in the previous round
+        wave_sync_lds();
+        load_rec();                        // records two rounds ahead (their ids were requested a round ago)
+        load_id(top - 3 * WAVE - lane);
+        if (32 < cnt) bwd_group<4>(st, tB0, tB1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, op.a[0], mono, tA0, tA1);
+        if (40 < cnt) bwd_group<5>(st, tB0, tB1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, op.a[0], mono, tA0, tA1);
+        if (48 < cnt) bwd_group<6>(st, tB0, tB1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, op.a[0], mono, tA0, tA1);
+        if (56 < cnt) bwd_group<7>(st, tB0, tB1, wCol, sX, accF, RA, lane, xw, topu, last, d0, d1, d2, nTb, op.a[0], mono, tA0, tA1);
+#pragma unroll
+        for (int t = 0; t < 6; t++) opS1[t] = op.a[1][t];
+        if (st.pend >= 0) {  // the round's last group: reduce it now (the flush below needs it)
+            wave_sync_lds();
+            red_park(red_group(RA, sX, lane), accF + 12 * 8 * st.pend, lane);
+            st.pend = -1;
+        }
+        const unsigned long long touched = st.touched;
         wave_sync_lds();
         if ((touched >> lane) & 1ull) {  // lane j turns staged splat j's sums into ONE 48-byte instance record (no atomics)
             const float4 v0 = sAcc[3 * lane], v1 = sAcc[3 * lane + 1], v2 = sAcc[3 * lane + 2];
@@ -415,6 +542,7 @@ __global__ __launch_bounds__(64, 3) void k_composite_bwd_mfma(int W, int H, int 
             dst[2] = make_float4(m0 * __builtin_amdgcn_rcpf(sop), 0.f, 0.f, 0.f);
             inst_pos[curSlot] = pp;
         }
+        sx = nx; sy = ny; sA_ = nAa; sB_ = nAb; sC_ = nCc; sop = nop; curSlot = nSl;
     }
 }
 
@@ -459,7 +587,7 @@ __global__ __launch_bounds__(64) void k_selftest(float *__restrict__ out) {
         const double px = (double)cx - 3.5 + (lane & 7), py = (double)cy - 3.5 + (lane >> 3);
         for (int j = 0; j < WAVE; j++) {
             const double dx = (double)sRec[j][0] - px, dy = (double)sRec[j][1] - py;
-            const double ref = (-0.5 * ((double)sRec[j][2] * dx * dx + (double)sRec[j][4] * dy * dy) - (double)sRec[j][3] * dx * dy) * GSR_LOG2E;
+            const double ref = (-0.5 * ((double)sRec[j][2] * dx * dx + (double)sRec[j][4] * dy * dy) - (double)sRec[j][3] * dx * dy) * GSR_LOG2E_D;
             e0 = fmaxf(e0, (float)(fabs((double)sP[j][lane] - ref) / (1.0 + fabs(ref))));
         }
     }
@@ -513,7 +641,7 @@ void gsr_launch_composite_fwd_mfma(int W, int H, int bx, int by, const GsrSplat 
                                    const GsrHeader *hdr, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_fwd_mfma, dim3(wgs), dim3(64), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
+    hipLaunchKernelGGL(k_composite_fwd_mfma, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
                        final_T, n_contrib, hdr);
 }
 
@@ -523,7 +651,7 @@ void gsr_launch_composite_bwd_mfma(int W, int H, int bx, int by, const GsrSplat 
                                    GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_bwd_mfma, dim3(wgs), dim3(64), 0, s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
+    hipLaunchKernelGGL(k_composite_bwd_mfma, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
                        final_T, n_contrib, goff, gpart, inst_pos, inst_grad, hdr);
 }
 
