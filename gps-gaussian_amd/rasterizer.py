@@ -132,7 +132,7 @@ def _learn(st, R, need, P):
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None  # ctypes converts a Python int to the void* argument
 
 
 class _HeaderRing:
@@ -184,6 +184,10 @@ def _ring(dev):
 
 
 def _prep(t, name, shape_tail, device):
+    # fast path (what the reference's callers pass): fp32, contiguous, on the device, right shape -- used as is (only its address is needed)
+    if (isinstance(t, torch.Tensor) and t.dtype is torch.float32 and t.device == device and t.is_contiguous()
+            and (shape_tail is None or (t.dim() == 2 and tuple(t.shape[1:]) == shape_tail)) and (shape_tail != (4,) or t.data_ptr() % 16 == 0)):
+        return t
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a tensor" % name)
     if t.device != device:
@@ -263,7 +267,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if mode != "none":
                 _drain_pending(st)
             cur_stream = torch.cuda.current_stream(dev)
-            stream = C.c_void_p(cur_stream.cuda_stream)
+            stream = cur_stream.cuda_stream
             ring = _ring(dev)
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -339,18 +343,21 @@ class _RasterizeGaussians(torch.autograd.Function):
             st = _dev_state(dev)
             if _check_mode() != "none":
                 _drain_pending(st, block=(_check_mode() == "deferred"))
-            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
             arena = ctx.grad_arena
             if arena is not None and all(a.dtype == torch.float32 and a.is_contiguous() and a.device == dev and tuple(a.shape) == (P, c)
                                          for a, c in zip(arena, (3, 3, 1, 3, 4))):
                 d_m3, d_col, d_op, d_sc, d_rot = arena
+                d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)
             else:
-                d_m3 = torch.empty((P, 3), dtype=torch.float32, device=dev)
-                d_col = torch.empty((P, 3), dtype=torch.float32, device=dev)
-                d_op = torch.empty((P, 1), dtype=torch.float32, device=dev)
-                d_sc = torch.empty((P, 3), dtype=torch.float32, device=dev)
-                d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
+                # one allocation, six contiguous gradient arrays carved out of it (quaternion gradient first: it is stored as float4)
+                buf = torch.empty((P * 17,), dtype=torch.float32, device=dev)
+                d_rot = buf[:4 * P].view(P, 4)
+                d_m3 = buf[4 * P:7 * P].view(P, 3)
+                d_m2 = buf[7 * P:10 * P].view(P, 3)
+                d_col = buf[10 * P:13 * P].view(P, 3)
+                d_sc = buf[13 * P:16 * P].view(P, 3)
+                d_op = buf[16 * P:].view(P, 1)
             if P > 0:
                 rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                       float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),

@@ -1,0 +1,109 @@
+"""RasterSession -- a torch-autograd-free host for the rasteriser C-ABI (include/gpsgs.h), for callers that drive forward and
+backward themselves (inference servers, C++/other-language hosts mirror it 1:1 -- tests/capi_host/capi_host_smoke.cpp -- and
+bench.py's headline step).
+
+What it is NOT: a different code path.  It enqueues exactly the kernels `rasterizer._RasterizeGaussians` enqueues, through the same
+two C-ABI entry points (gsr_forward_notify, gsr_backward), with the same exact capacity policy (the binning scan publishes the
+instance count to pinned host memory; an overflow is repaired by a transparent re-run).  What it leaves out is what PyTorch adds
+around them per call: the autograd Function / engine round trip (~120 us per forward+backward on an idle MI355X host, measured
+with tools/host_profile.py), tensor allocations (outputs, workspace and gradient buffers are allocated once per (P, W, H)) and
+argument normalisation.  Host cost per forward+backward: two ctypes calls (~35 us, almost all of it the HIP launches themselves).
+
+Semantics follow the reference call at /root/reference/gaussian_renderer/__init__.py:36-62 (precomputed colours, scales + rotations).
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from . import rasterizer as RZ
+
+
+class RasterSession:
+    def __init__(self, P, width, height, device, training=True):
+        self.P, self.W, self.H = int(P), int(width), int(height)
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("gps_gaussian_amd: RasterSession needs a GPU device (no CPU path exists)")
+        self.training = bool(training)
+        self.lib = _capi.lib()
+        d, f32 = self.dev, torch.float32
+        self.color = torch.empty((3, self.H, self.W), dtype=f32, device=d)
+        self.radii = torch.empty((self.P,), dtype=torch.int32, device=d)
+        self.ws, self.cap, self.nbytes = None, 0, 0
+        self._in = None
+        if self.training:
+            # one buffer, six contiguous gradient arrays carved out of it
+            P_ = max(self.P, 1)
+            self._gbuf = torch.empty((P_ * 17 + 64,), dtype=f32, device=d)
+            o, self.grads = 0, {}
+            for name, c in (("rotations", 4), ("means3D", 3), ("means2D", 3), ("colors", 3), ("scales", 3), ("opacities", 1)):
+                o = (o + 3) // 4 * 4  # 16-byte alignment (the quaternion gradient is stored as float4)
+                self.grads[name] = self._gbuf[o:o + self.P * c].view(self.P, c)
+                o += P_ * c
+        self._ws_bytes = self.lib.gsr_workspace_bytes if self.training else self.lib.gsr_workspace_bytes_forward_only
+
+    def _ensure_ws(self, cap):
+        if self.ws is None or cap != self.cap:
+            self.nbytes = self._ws_bytes(self.P, self.W, self.H, cap)
+            self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=self.dev)
+            self.cap = cap
+
+    @staticmethod
+    def _chk(t, n, name):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+            raise RuntimeError("gps_gaussian_amd: RasterSession expects %s as a contiguous fp32 GPU tensor of %d elements" % (name, n))
+        return t.data_ptr()
+
+    def forward(self, means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg, tanfovx, tanfovy, scale_modifier=1.0):
+        """-> (color[3,H,W], radii[P]) (the session's own buffers: valid until the next forward).  Enqueues on the current stream."""
+        P, W, H, lib = self.P, self.W, self.H, self.lib
+        ptrs = (self._chk(means3D, 3 * P, "means3D"), self._chk(colors, 3 * P, "colors"), self._chk(opacities, P, "opacities"),
+                self._chk(scales, 3 * P, "scales"), self._chk(rotations, 4 * P, "rotations"))
+        cam = (self._chk(viewmatrix, 16, "viewmatrix"), self._chk(projmatrix, 16, "projmatrix"), self._chk(bg, 3, "bg"))
+        fl = (float(scale_modifier), float(tanfovx), float(tanfovy))
+        st = RZ._dev_state(self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        stream = cur.cuda_stream
+        ring = RZ._ring(self.dev)
+        family = RZ._composite_flag()
+        flags = RZ._extra_flags | family
+        cap = max(self.cap, RZ._capacity_for(st, P))
+        while True:
+            self._ensure_ws(cap)
+            if P == 0:
+                _capi.check(lib.gsr_forward(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
+                                            self.nbytes, cap, flags, stream), "gsr_forward")
+                break
+            hdr, w32, hdr_ptr, seq = ring.next_notify()
+            skip_large = not st.get("big_bins", False)
+            f = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
+            _capi.check(lib.gsr_forward_notify(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
+                                               self.nbytes, cap, f, stream, hdr_ptr, seq), "gsr_forward_notify")
+            RZ._wait_notify(w32, seq, cur)
+            R, overflow, need = RZ._decode(hdr)
+            RZ._learn(st, R, need, P)
+            if int(w32[3]) > 768:
+                st["big_bins"] = True
+            if not overflow:
+                break
+            cap = RZ._capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
+        self._in = (ptrs, fl, cam, family, (means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg))  # keeps the inputs alive
+        return self.color, self.radii
+
+    def backward(self, dL_dpix):
+        """dL_dpix[3,H,W] fp32 contiguous -> dict of gradient tensors (the session's own buffers: valid until the next backward)."""
+        if not self.training:
+            raise RuntimeError("gps_gaussian_amd: this RasterSession was created with training=False (no backward workspace)")
+        if self._in is None:
+            raise RuntimeError("gps_gaussian_amd: RasterSession.backward() without a forward()")
+        ptrs, fl, cam, family, _keep = self._in
+        g = self._chk(dL_dpix, 3 * self.W * self.H, "dL_dpix")
+        G = self.grads
+        if self.P > 0:
+            rc = self.lib.gsr_backward(self.P, self.W, self.H, *ptrs, *fl, *cam, self.radii.data_ptr(), g, G["means3D"].data_ptr(),
+                                       G["means2D"].data_ptr(), G["colors"].data_ptr(), G["opacities"].data_ptr(), G["scales"].data_ptr(),
+                                       G["rotations"].data_ptr(), self.ws.data_ptr(), self.nbytes, self.cap, RZ._extra_flags | family,
+                                       torch.cuda.current_stream(self.dev).cuda_stream)
+            _capi.check(rc, "gsr_backward")
+        return G

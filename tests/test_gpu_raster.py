@@ -545,3 +545,41 @@ def test_skipped_large_sort_launch_is_detected_and_repaired():
     solid2, _ = touched_by_fragile(o2)
     assert np.abs(img2 - oimg2).max(0)[solid2].max() <= RGB_TOL
     RZ._state.clear()
+
+
+def test_raster_session_matches_the_autograd_module_bit_for_bit(monkeypatch):
+    """RasterSession (the C-ABI driven directly: preallocated buffers, no autograd round trip -- bench.py's headline host) enqueues
+    the same kernels as the drop-in autograd module: image, radii and all six gradients are bit-identical, also when its first
+    capacity guess overflows and the forward is re-run, and on a second view of a different size through a second session."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    from gps_gaussian_amd.session import RasterSession
+    dev = torch.device("cuda:0")
+    for g in (S.make_scene(256, 30000), S.make_uniform_cloud(5000, 129, 96, seed=9, scale_med=0.05)):
+        H, W, P = g["H"], g["W"], g["means3D"].shape[0]
+        dpix = np.random.default_rng(4).standard_normal((3, H, W)).astype(np.float32)
+        img, radii, grads, _ = hip_render(g, dpix)
+        t = {k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32)).to(dev) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+        cam = [torch.from_numpy(g[k]).to(dev) for k in ("view", "proj", "bg")]
+        sess = RasterSession(P, W, H, dev)
+        calls = []
+        real = RZ._capacity_for
+
+        def tiny_first(st, P_):
+            calls.append(1)
+            return 2048 if len(calls) == 1 else real(st, P_)
+
+        monkeypatch.setattr(RZ, "_capacity_for", tiny_first)
+        for rep in range(2):   # first call: overflow + repair; second: steady state with the learnt capacity
+            color, rad = sess.forward(t["means3D"], t["colors"], t["opacities"].reshape(-1), t["scales"], t["rotations"], *cam, g["tanfovx"], g["tanfovy"])
+            G = sess.backward(torch.from_numpy(dpix).to(dev))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(color.cpu().numpy(), img)
+            np.testing.assert_array_equal(rad.cpu().numpy(), radii)
+            for k in grads:
+                np.testing.assert_array_equal(G[k].cpu().numpy(), grads[k])
+        assert len(calls) >= 2
+        monkeypatch.setattr(RZ, "_capacity_for", real)
+    with pytest.raises(RuntimeError):
+        RasterSession(10, 16, 16, "cpu")
