@@ -223,7 +223,7 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
     {
         StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);
-        gsr_launch_preprocess_bwd(b, splats, goff, gscan_part, inst_pos, inst_grad, s);
+        gsr_launch_preprocess_bwd(b, splats, goff, gscan_part, inst_pos, inst_grad, hdr, s);
     }
     return check(s, flags);
 }

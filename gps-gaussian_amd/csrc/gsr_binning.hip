@@ -135,14 +135,15 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         }
         __syncthreads();
     }
-    uint32_t pre_sum = 0, pre_busy = 0, tot_sum = 0, tot_busy = 0, tot_max = 0;
+    uint32_t pre_sum = 0, pre_busy = 0, tot_busy = 0, tot_max = 0;
+    uint64_t tot_sum = 0;  // 64-bit: a total beyond 2^32 must read as an overflow, not wrap below the capacity
     for (int i = 0; i < nblocks; i++) {  // a handful of uint4
         const uint4 p = FUSED ? sp[i] : part[i];
         if (i < (int)blockIdx.x) { pre_sum += p.x; pre_busy += p.y; }
         tot_sum += p.x; tot_busy += p.y; tot_max = p.z > tot_max ? p.z : tot_max;
     }
     if (blockIdx.x == 0 && tid == 0) {
-        bin_offset[NB] = tot_sum;
+        bin_offset[NB] = (uint32_t)tot_sum;
         hdr->num_rendered = tot_sum;
         // a list longer than 1024 entries while the caller skipped the large-list sort launch is reported like an overflow:
         // every later kernel exits, the caller sees max_tile_count > 1024 and calls again with that launch
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
             // capacity while scatter / sort / compositing are still running (no copy engine, no event in the stream)
             const uint32_t ovf = ovf_b ? 1u : 0u;
             volatile uint32_t *h = host_hdr;
-            h[0] = tot_sum; h[1] = 0u; h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = 0u;
+            h[0] = (uint32_t)tot_sum; h[1] = (uint32_t)(tot_sum >> 32); h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = 0u;
             __threadfence_system();
             __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this word
         }

@@ -335,4 +335,4 @@ struct GsrBwdParams {
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dscales, *dL_drotations;
 };
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
-                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, hipStream_t s);
+                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s);

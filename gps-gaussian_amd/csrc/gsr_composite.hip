@@ -31,9 +31,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_fwd(int W, int H, int 
     __shared__ float4 sA[WAVES][WAVE];
     __shared__ float4 sB[WAVES][WAVE];
     __shared__ float sC[WAVES][WAVE];
-    if (hdr->overflow) return;
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    if (hdr->overflow) {  // nothing can be rendered from truncated lists: a deterministic zero image instead of uninitialised memory
+        fwd_write_blank(g, W, H, out_color, final_T, n_contrib);
+        return;
+    }
     const float pxf = (float)g.px, pyf = (float)g.py;
     float4 *wA = sA[g.wid], *wB = sB[g.wid];
     float *wC = sC[g.wid];

@@ -48,6 +48,16 @@ __device__ __forceinline__ WaveGeom wave_geom(int W, int H, int bx, const uint32
     return g;
 }
 
+// overflowed forward: this wave's pixels become a defined blank (zero colour, T = 1, no contributor)
+__device__ __forceinline__ void fwd_write_blank(const WaveGeom &g, int W, int H, float *__restrict__ out_color, float *__restrict__ final_T,
+                                                uint32_t *__restrict__ n_contrib) {
+    if (!g.inside) return;
+    const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
+    out_color[q] = 0.f; out_color[npix + q] = 0.f; out_color[2 * npix + q] = 0.f;
+    final_T[q] = 1.f;
+    n_contrib[q] = 0u;
+}
+
 // The exponent of a (pixel, splat) pair in log2 units, from a conic that was pre-scaled when the splat was staged
 // (A2 = -0.5 log2(e) A, B2 = -log2(e) B, C2 = -0.5 log2(e) C): 6 instructions instead of 8 and v_exp_f32 directly.  Forward and backward
 // MUST evaluate this same sequence (explicit fma: no contraction choices left to the compiler) so that both take the same

@@ -196,9 +196,12 @@ __global__ __launch_bounds__(64, 4) void k_composite_fwd_mfma(int W, int H, int 
                                                            float *__restrict__ out_color, float *__restrict__ final_T,
                                                            uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sCol[2][WAVE];  // {opacity, r, g, b} of the 64 staged splats, double buffered (round parity)
-    if (hdr->overflow) return;
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    if (hdr->overflow) {  // nothing can be rendered from truncated lists: a deterministic zero image instead of uninitialised memory
+        fwd_write_blank(g, W, H, out_color, final_T, n_contrib);
+        return;
+    }
     g.r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0);  // the list range is wave-uniform: keep it (and every loop bound and
     g.r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);  // lane mask derived from it) on the scalar unit
     const int lane = g.lane;

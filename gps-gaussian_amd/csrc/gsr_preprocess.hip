@@ -217,12 +217,16 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
 
 __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrSplat *__restrict__ splats,
                                                         const uint32_t *__restrict__ goff, const uint32_t *__restrict__ gpart,
-                                                        const uint32_t *__restrict__ inst_pos, const GsrGradAcc *__restrict__ inst_grad) {
+                                                        const uint32_t *__restrict__ inst_pos, const GsrGradAcc *__restrict__ inst_grad,
+                                                        const GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= q.P) return;
+    // an overflowed forward rendered nothing: inst_pos / inst_grad were never written (and the slot range may not even fit the
+    // workspace), so every Gaussian gets an exact zero gradient instead of a gather over garbage
+    const bool rendered = hdr->overflow == 0u;
     float dm[3] = {0.f, 0.f, 0.f}, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
-    if (q.radii[i] > 0) {
+    if (rendered && q.radii[i] > 0) {
         const Cam cam = load_cam(q.view, q.proj);
         // the per-Gaussian inputs of the chain rule are requested BEFORE the record gather, so they travel alongside it
         float in_p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
@@ -373,7 +377,7 @@ void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hi
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
-                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, hipStream_t s) {
+                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, goff, gpart, inst_pos, inst_grad);
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, goff, gpart, inst_pos, inst_grad, hdr);
 }

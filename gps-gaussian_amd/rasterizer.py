@@ -297,6 +297,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                         st["big_bins"] = True  # sticky, with margin: from now on the large-list sort is always launched
                     if not overflow:
                         break
+                    if cap >= 0x7fffffff:
+                        raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
+                                           "layout can address" % R)
                     cap = _capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
                     continue
                 flags &= ~_capi.GSR_FLAG_NO_LARGE_SORT  # only the early-notification path can verify that shortcut
@@ -319,6 +322,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _learn(st, R, need, P)
                 if not overflow:
                     break
+                if cap >= 0x7fffffff:
+                    raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
+                                       "layout can address" % R)
                 cap = _capacity_for(st, P)  # grown by _learn; re-run the whole (cheap) forward
         ctx.raster_settings = rs
         ctx.cap = cap

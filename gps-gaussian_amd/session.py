@@ -87,6 +87,8 @@ class RasterSession:
                 st["big_bins"] = True
             if not overflow:
                 break
+            if cap >= 0x7fffffff:
+                raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace layout can address" % R)
             cap = RZ._capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
         self._in = (ptrs, fl, cam, family, (means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg))  # keeps the inputs alive
         return self.color, self.radii

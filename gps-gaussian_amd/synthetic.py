@@ -48,19 +48,16 @@ def source_camera(res, angle_deg, radius=2.0, pitch_deg=-8.0, look_at=(0.0, 0.85
 
 
 def projection_matrix(znear, zfar, K, h, w):
-    """Off-centre perspective matrix, z in [0,1], P[3,2] = 1 (restates lib/graphics_utils.py:31-48)."""
-    near_fx, near_fy = znear / K[0, 0], znear / K[1, 1]
-    left, right = -(w - K[0, 2]) * near_fx, K[0, 2] * near_fx
-    bottom, top = (K[1, 2] - h) * near_fy, K[1, 2] * near_fy
-    P = np.zeros((4, 4), np.float32)
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = 1.0
-    P[2, 2] = zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    return P
+    """Off-centre pinhole projection with z in [0, 1] and w_clip = z_view, straight from the intrinsics:
+    x_ndc = (2 fx x / z + (2 cx - w)) / w,  y_ndc = (2 fy y / z + (2 cy - h)) / h  (what lib/graphics_utils.py:31-48 evaluates through
+    the near-plane frustum bounds; tests/golden/camera_golden.npz pins the agreement)."""
+    fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+    P = np.zeros((4, 4), np.float64)
+    P[0] = (2.0 * fx / w, 0.0, (2.0 * cx - w) / w, 0.0)
+    P[1] = (0.0, 2.0 * fy / h, (2.0 * cy - h) / h, 0.0)
+    P[2] = (0.0, 0.0, zfar / (zfar - znear), -zfar * znear / (zfar - znear))
+    P[3] = (0.0, 0.0, 1.0, 0.0)
+    return P.astype(np.float32)
 
 
 def novel_camera(intr0, extr0, intr1, extr1, ratio, width, height, znear=0.01, zfar=100.0, hr=False):
@@ -232,4 +229,37 @@ def make_uniform_cloud(n_gauss, W, H, seed=SEED, z_range=(0.5, 6.0), scale_med=0
         opacities=(1 / (1 + np.exp(-rng.normal(0.0, 2.0, (n_gauss, 1))))).astype(np.float32),
         view=wvt, proj=(wvt @ proj).astype(np.float32), campos=np.zeros(3, np.float32), W=W, H=H,
         tanfovx=W / (2 * fx), tanfovy=H / (2 * fx), bg=np.array([0.1, 0.2, 0.3], np.float32),
+    )
+
+
+def make_clamp_cloud(n_gauss, W, H, seed=SEED, z_range=(0.5, 4.0), scale_med=0.08, fov_deg=60.0, quat_norm=(0.5, 2.0), spread=0.6,
+                     opacity_logit=(-2.0, 1.0)):
+    """Stress variant for the branches the other generators leave cold: a ROTATED and TRANSLATED camera (general view matrix),
+    centres spread `spread` image widths beyond every image border -- far outside the 1.3 * tanfov guard band, so the clamp of the
+    view-space x/y and its zeroed gradient terms fire -- large splats (so that clamped ones still reach the image), and
+    quaternions that are NOT unit length (the rasteriser must not re-normalise them)."""
+    rng = np.random.default_rng(seed)
+    fx = 0.5 * W / math.tan(math.radians(fov_deg) / 2)
+    K = np.array([[fx, 0, W / 2 - 2.7], [0, fx, H / 2 + 1.9], [0, 0, 1]], np.float32)
+    z = rng.uniform(z_range[0], z_range[1], n_gauss)
+    u = rng.uniform(-spread * W, (1 + spread) * W, n_gauss)
+    v = rng.uniform(-spread * H, (1 + spread) * H, n_gauss)
+    xc = np.stack([(u - K[0, 2]) * z / fx, (v - K[1, 2]) * z / fx, z], 1)
+    # camera pose: rotation by ~25 degrees about a tilted axis, translated off the origin
+    ax = np.array([0.3, 1.0, 0.2]); ax /= np.linalg.norm(ax)
+    Rcw = Rot.from_rotvec(ax * math.radians(25.0)).as_matrix()          # world -> camera rotation
+    tcw = np.array([0.4, -0.25, 0.6])
+    xw = (xc - tcw) @ Rcw                                              # x_c = Rcw x_w + tcw  =>  x_w = Rcw^T (x_c - tcw)
+    w2c = np.eye(4); w2c[:3, :3] = Rcw; w2c[:3, 3] = tcw
+    wvt = w2c.T.astype(np.float32)
+    q = rng.standard_normal((n_gauss, 4))
+    q *= (rng.uniform(quat_norm[0], quat_norm[1], (n_gauss, 1)) / np.linalg.norm(q, axis=1, keepdims=True))
+    proj = projection_matrix(0.01, 100.0, K, H, W).T
+    campos = (-Rcw.T @ tcw).astype(np.float32)
+    return dict(
+        means3D=xw.astype(np.float32), colors=rng.uniform(0, 1, (n_gauss, 3)).astype(np.float32), rotations=q.astype(np.float32),
+        scales=np.exp(rng.normal(math.log(scale_med), 0.5, (n_gauss, 3))).astype(np.float32),
+        opacities=(1 / (1 + np.exp(-rng.normal(opacity_logit[0], opacity_logit[1], (n_gauss, 1))))).astype(np.float32),
+        view=wvt, proj=(wvt @ proj).astype(np.float32), campos=campos, W=W, H=H,
+        tanfovx=W / (2 * fx), tanfovy=H / (2 * fx), bg=np.array([0.3, 0.1, 0.2], np.float32),
     )

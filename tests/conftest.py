@@ -45,7 +45,7 @@ def oracle_render(scene, kind="f32", decisions=None):
     o = OracleRasterizer(kind)
     img, radii = o.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
                            scene["view"], scene["proj"], scene["W"], scene["H"], scene["tanfovx"], scene["tanfovy"], scene["bg"],
-                           decisions=decisions)
+                           scale_modifier=float(scene.get("scale_modifier", 1.0)), decisions=decisions)
     return o, img, radii
 
 
@@ -61,7 +61,7 @@ def hip_render(scene, dpix=None, debug=False):
     m2 = torch.zeros_like(t["means3D"], requires_grad=dpix is not None)
     rs = RZ.GaussianRasterizationSettings(
         image_height=scene["H"], image_width=scene["W"], tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"],
-        bg=torch.from_numpy(scene["bg"]).to(dev), scale_modifier=1.0, viewmatrix=torch.from_numpy(scene["view"]).to(dev),
+        bg=torch.from_numpy(scene["bg"]).to(dev), scale_modifier=float(scene.get("scale_modifier", 1.0)), viewmatrix=torch.from_numpy(scene["view"]).to(dev),
         projmatrix=torch.from_numpy(scene["proj"]).to(dev), sh_degree=3, campos=torch.from_numpy(scene["campos"]).to(dev),
         prefiltered=False, debug=debug)
     img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=None, colors_precomp=t["colors"],
@@ -78,7 +78,16 @@ def hip_render(scene, dpix=None, debug=False):
     return img.detach().cpu().numpy(), radii.cpu().numpy(), grads, info
 
 
-def touched_by_fragile(oracle, thresh=1e-4):
+def clamp_active(scene):
+    """Mask of Gaussians whose view-space x/z or y/z lies outside the 1.3 * tanfov guard band (the EWA clamp and its zeroed gradient
+    terms are active for them)."""
+    w2c = np.asarray(scene["view"], np.float64).T
+    pc = np.asarray(scene["means3D"], np.float64) @ w2c[:3, :3].T + w2c[:3, 3]
+    z = np.where(np.abs(pc[:, 2]) < 1e-12, 1e-12, pc[:, 2])
+    return (np.abs(pc[:, 0] / z) > 1.3 * scene["tanfovx"]) | (np.abs(pc[:, 1] / z) > 1.3 * scene["tanfovy"])
+
+
+def touched_by_fragile(oracle, thresh=1e-5):
     """Mask of Gaussians whose footprint covers a pixel that sits on a branch threshold (alpha=1/255, T=1e-4)."""
     frag = oracle.fragility()
     geom = oracle.geom()
@@ -87,3 +96,32 @@ def touched_by_fragile(oracle, thresh=1e-4):
     for y, x in zip(fy, fx):
         touched |= (np.abs(geom["xy"][:, 0] - x) <= geom["radii"] + 1) & (np.abs(geom["xy"][:, 1] - y) <= geom["radii"] + 1) & (geom["radii"] > 0)
     return frag > thresh, touched
+
+
+def parity_report(name, img, oimg, grads, og, solid, touched, extra=None, rgb_tol=1e-4, grad_tol=1e-3):
+    """What SURVEY.md section 7 ("Hard parts") asks every parity test to REPORT, not just assert: max abs RGB error and the number of
+    pixels over tolerance (all pixels / pixels away from a branch threshold), and per gradient array the max normalised error
+    |a - ref| / (|ref| + tol * max|ref|) over Gaussians that touch no fragile pixel, its 99.9 % quantile over all elements, and the
+    number of Gaussians with any element over tolerance.  Printed (pytest -s) and appended to gpurun_out/parity_report.jsonl."""
+    import json
+    err = np.abs(img - oimg).max(0)
+    rep = dict(test=name, pixels=int(err.size), fragile_pixels=int((~solid).sum()), rgb_max_err=float(err.max()),
+               rgb_max_err_solid=float(err[solid].max()) if solid.any() else 0.0, pixels_over_tol=int((err > rgb_tol).sum()),
+               gaussians=int(touched.size), gaussians_touching_fragile=int(touched.sum()))
+    if grads is not None:
+        rep["grads"] = {}
+        for k in grads:
+            s_ = np.abs(og[k]).max() + 1e-30
+            e = np.abs(grads[k] - og[k]) / (np.abs(og[k]) + grad_tol * s_)
+            over = (e > grad_tol).any(axis=-1)
+            rep["grads"][k] = dict(max_err_untouched=float(e[~touched].max()) if (~touched).any() else 0.0, q999=float(np.quantile(e, 0.999)),
+                                   gaussians_over_tol=int(over.sum()), gaussians_over_tol_untouched=int((over & ~touched).sum()))
+    if extra:
+        rep.update(extra)
+    line = json.dumps(rep)
+    print(line)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
+            f.write(line + "\n")
+    return rep

@@ -41,6 +41,28 @@ def test_backward_matches_independent_autograd(seed, W, H, n, scale):
         np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
 
 
+@pytest.mark.parametrize("seed,W,H,n,mod", [(3, 128, 128, 2000, 1.0), (4, 96, 80, 700, 0.5)])
+def test_backward_matches_independent_autograd_with_the_fov_clamp_active(seed, W, H, n, mod):
+    """Same pin on the branches the uniform cloud leaves cold: general (rotated + translated) view matrix, centres far outside the
+    1.3 * tanfov guard band (clamped view-space x/y with zeroed gradient terms), non-unit quaternions, scale_modifier != 1."""
+    from conftest import clamp_active
+    g = S.make_clamp_cloud(n, W, H, seed=seed, scale_med=0.08 / mod)
+    g["scale_modifier"] = mod
+    dpix = np.random.default_rng(seed).standard_normal((3, H, W))
+    o, img, radii = oracle_render(g, "f64")
+    gr = o.backward(dpix)
+    img2, radii2, gr2 = grads_ref(g, W, H, g["tanfovx"], g["tanfovy"], dpix, scale_modifier=mod)
+    assert (radii == radii2).all()
+    contributing = np.abs(gr2["means3D"]).max(1) > 0
+    frac = (clamp_active(g) & contributing).sum() / max(1, contributing.sum())
+    qn = np.linalg.norm(g["rotations"], axis=1)
+    print("contributing %d of %d, clamp active on %.0f %% of them, |q| in [%.2f, %.2f]" % (contributing.sum(), n, 100 * frac, qn.min(), qn.max()))
+    assert contributing.sum() >= n // 10 and frac >= 0.05 and qn.min() < 0.6 and qn.max() > 1.8
+    np.testing.assert_allclose(img, img2, atol=1e-12)
+    for k in gr:
+        np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
+
+
 def test_fp32_and_fp64_builds_agree_on_config1():
     """BASELINE config 1 (256^2, ~30k Gaussians, CPU only): the two builds agree away from branch thresholds."""
     g = S.make_scene(256, 30000)
