@@ -33,3 +33,21 @@ def test_bench_json_line_has_the_contract_fields():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
     assert d["stage2_path"]["iters_per_s"] > 0 and "error" not in (d["hip_graph_replay"] or {})
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The multi-rank bench path (env rendezvous, per-rank workload, barrier + MAX-over-ranks timing, whole-job aggregate, agreed failure
+    handling of the stage-2 leg with its gradient all-reduce) exercised on the 1-GPU box: two ranks share device 0
+    (GPSGS_BENCH_SINGLE_DEVICE=1) and talk over gloo instead of RCCL.  No 2/4/8-GPU number exists; this only proves the code path."""
+    env = dict(os.environ, GPSGS_BENCH_SINGLE_DEVICE="1", GPSGS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--res", "256", "--gaussians", "30000"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02     # whole-job aggregate: both ranks' views / the slowest rank's time
+    assert d["cpu_baseline"] is None                  # rank 0 at N = 1 only
+    assert d["stage2_path"]["n_gpus"] == 2 and d["stage2_path"]["iters_per_s"] > 0

@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Data-parallel launcher around the reference's UNMODIFIED stage-2 trainer.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        tools/launch_stage2.py --reference /path/to/GPS-Gaussian [--config config/stage2.yaml] [--steps K] [KEY VALUE ...]
+
+The reference trains on ONE GPU (/root/reference/train_stage2.py:27-55 has no distributed code).  Its render path shards by stereo
+pair with no data-path collective, so data parallelism is one process per GPU, each running the reference's own `Trainer` on its
+shard of the dataset, plus ONE exchange step per iteration: a mean all-reduce of the 5,144,408 network gradients (20.6 MB, one
+32 MiB bucket -- xGMI is point-to-point, ring collectives are per-link bound, so one large message) over RCCL (backend "nccl";
+"gloo" on CPU).  Nothing in the reference is edited; this file only
+  * puts gps-gaussian_amd/dropin (the MI355X rasteriser / correlation sampler under the reference's import names) and then the
+    reference on sys.path, plus stand-ins for yacs / cv2 / tensorboard when -- and only when -- the real packages are missing;
+  * imports `train_stage2` WITHOUT executing its `__main__` block and repeats that block (train_stage2.py:183-207), with one repair the
+    reference needs anyway: `Trainer` reads a module-global `cfg` (train_stage2.py:44,76,101,123) that only exists when the file runs
+    as a script, so the launcher sets it on the imported module;
+  * swaps the module's `DataLoader` for one that shards the training set with a `DistributedSampler` (per-rank batch size =
+    cfg.batch_size: weak scaling; the validation loader stays whole and only rank 0 evaluates);
+  * hooks the exchange step into the one place every iteration passes between backward and the optimizer:
+    `GradScaler.unscale_(optimizer)` (train_stage2.py:84) first all-reduces the (still scaled) gradients -- parameters that received
+    none (the reference constructs gru16 / gru32 but never runs them, core/update.py:105-106) are sent as zeros, which is what
+    DDP(find_unused_parameters=True) would amount to -- so clip_grad_norm_, the inf check and the step see identical numbers on
+    every rank and the GradScaler's skip decisions agree;
+  * keeps logging, checkpoints and previews on rank 0 (the other ranks get a silent logger and no-op save / eval), seeds
+    every rank differently for data order but identically for the model (torch.manual_seed(1314) before `Trainer(cfg)` as the
+    reference does, rank offset afterwards).
+"""
+import argparse
+import importlib
+import json
+import logging
+import os
+import sys
+import types
+from datetime import datetime
+from pathlib import Path
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _install_shims():
+    """Stand-ins for packages the MI355X image lacks; never shadows a real installation."""
+    for name in ("yacs", "cv2"):
+        try:
+            importlib.import_module(name)
+        except ImportError:
+            p = os.path.join(HERE, "shims")
+            if p not in sys.path:
+                sys.path.append(p)  # behind everything else
+    try:
+        importlib.import_module("torch.utils.tensorboard")
+    except Exception:  # noqa: BLE001  (ImportError from the missing `tensorboard` package)
+        m = types.ModuleType("torch.utils.tensorboard")
+
+        class SummaryWriter:
+            """Scalars as JSON lines (events.jsonl) instead of TensorBoard event files."""
+
+            def __init__(self, log_dir=None, **_):
+                self.f = None
+                if log_dir:
+                    Path(log_dir).mkdir(parents=True, exist_ok=True)
+                    self.f = open(os.path.join(log_dir, "events.jsonl"), "a")
+
+            def add_scalar(self, tag, value, step=None, **_):
+                if self.f:
+                    self.f.write(json.dumps({"tag": tag, "value": float(value), "step": None if step is None else int(step)}) + "\n")
+                    self.f.flush()
+
+            def close(self):
+                if self.f:
+                    self.f.close()
+                    self.f = None
+
+        m.SummaryWriter = SummaryWriter
+        sys.modules["torch.utils.tensorboard"] = m
+
+
+class _SilentLogger:
+    """What ranks > 0 hand to the reference's `self.logger`: same methods, no files."""
+
+    class _W:
+        def add_scalar(self, *a, **k):
+            pass
+
+        def close(self):
+            pass
+
+    def __init__(self):
+        self.writer, self.total_steps = self._W(), 0
+
+    def push(self, metrics):
+        self.total_steps += 1
+
+    def write_dict(self, results, write_step):
+        pass
+
+    def close(self):
+        pass
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--reference", required=True, help="checkout of aipixel/GPS-Gaussian (unmodified)")
+    ap.add_argument("--config", default="config/stage2.yaml", help="relative to --reference")
+    ap.add_argument("--steps", type=int, default=None, help="override cfg.num_steps")
+    ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo")
+    ap.add_argument("--exp-root", default=None, help="where experiments/<name>/ goes (default: the reference's cwd-relative 'experiments')")
+    ap.add_argument("--hook", default=None, help="python file exec'd after `train_stage2` is imported and before Trainer(cfg) is built, with TS (the "
+                                                 "module), cfg, rank, world in scope: synthetic data sets, smoke tests")
+    ap.add_argument("overrides", nargs="*", help="KEY VALUE pairs merged into the config (yacs merge_from_list syntax)")
+    args = ap.parse_args(argv)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import gps_gaussian_amd  # noqa: F401
+    from gps_gaussian_amd import DROPIN_DIR
+    from gps_gaussian_amd import dist as D
+
+    ref = os.path.abspath(args.reference)
+    rank, local_rank, world = D.env_rank()
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if use_cuda else None
+    D.init(backend=args.backend, device=dev)  # no-op at world size 1
+
+    _install_shims()
+    sys.path.insert(0, ref)
+    sys.path.insert(0, DROPIN_DIR)  # `import diff_gaussian_rasterization` / `import corr_sampler` -> the MI355X kernels
+    os.chdir(ref)                   # the reference uses cwd-relative paths ("config/stage2.yaml", file_backup's 'core', 'lib', ...)
+
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING,
+                        format="%(asctime)s %(levelname)-8s [rank " + str(rank) + " %(filename)s:%(lineno)d] %(message)s")
+    TS = importlib.import_module("train_stage2")  # defines Trainer; its __main__ block does not run
+
+    # ---- the reference's __main__ block (train_stage2.py:183-207) ------------------------------------------------------------
+    cfg = TS.config()
+    cfg.load(args.config)
+    cfg = cfg.get_cfg()
+    cfg.defrost()
+    if args.overrides:
+        cfg.merge_from_list(args.overrides)
+    if args.steps is not None:
+        cfg.num_steps = args.steps
+    dt = datetime.today()
+    cfg.exp_name = "%s_%s%s" % (cfg.name, str(dt.month).zfill(2), str(dt.day).zfill(2))
+    exp = os.path.join(args.exp_root or "experiments", cfg.exp_name)
+    cfg.record.ckpt_path, cfg.record.show_path = "%s/ckpt" % exp, "%s/show" % exp
+    cfg.record.logs_path, cfg.record.file_path = "%s/logs" % exp, "%s/file" % exp
+    cfg.freeze()
+    if rank == 0:
+        for path in (cfg.record.ckpt_path, cfg.record.show_path, cfg.record.logs_path, cfg.record.file_path):
+            Path(path).mkdir(exist_ok=True, parents=True)
+        TS.file_backup(cfg.record.file_path, cfg, train_script="train_stage2.py")
+    D.barrier(local_rank if use_cuda else None)
+    TS.cfg = cfg  # Trainer's methods read this module global (train_stage2.py:44,76,101,123)
+
+    # ---- shard the training set ---------------------------------------------------------------------------------------------------
+    samplers = []
+    RealLoader = TS.DataLoader
+
+    from torch.utils.data.distributed import DistributedSampler
+
+    class EpochSampler(DistributedSampler):
+        """Every time the reference re-creates its iterator (train_stage2.py:157-160) a new epoch's shuffle starts."""
+        _epoch_no = 0
+
+        def __iter__(self):
+            self.set_epoch(self._epoch_no)
+            self._epoch_no += 1
+            return super().__iter__()
+
+    def sharded_loader(dataset, batch_size=1, shuffle=False, **kw):
+        if world > 1 and shuffle:  # the training loader (the validation loader is built with shuffle=False and stays whole)
+            s = EpochSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=1314, drop_last=True)
+            samplers.append(s)
+            return RealLoader(dataset, batch_size=batch_size, shuffle=False, sampler=s, **kw)
+        return RealLoader(dataset, batch_size=batch_size, shuffle=shuffle, **kw)
+
+    TS.DataLoader = sharded_loader
+    if rank != 0:
+        TS.Logger = lambda scheduler, rec: _SilentLogger()
+        TS.tqdm = lambda it, *a, **k: it
+
+    if args.hook:
+        exec(compile(open(args.hook).read(), args.hook, "exec"), {"TS": TS, "cfg": cfg, "rank": rank, "world": world, "__name__": "launch_stage2_hook"})
+
+    torch.manual_seed(1314)  # identical initial weights on every rank (train_stage2.py:206-207)
+    np.random.seed(1314)
+    trainer = TS.Trainer(cfg)
+    torch.manual_seed(1314 + 1000 * rank)  # from here on: per-rank randomness
+    np.random.seed(1314 + 1000 * rank)
+
+    # ---- the one exchange step ------------------------------------------------------------------------------------------------------
+    reducer = D.GradAllReducer(trainer.model.parameters())
+    real_unscale = trainer.scaler.unscale_
+
+    def unscale_after_allreduce(optimizer):
+        reducer()  # mean over ranks of the (scaled) gradients; unused parameters travel as zeros
+        return real_unscale(optimizer)
+
+    trainer.scaler.unscale_ = unscale_after_allreduce
+    if rank != 0:
+        trainer.save_ckpt = lambda *a, **k: None
+        trainer.run_eval = lambda *a, **k: None
+    trainer.train()
+    D.barrier(local_rank if use_cuda else None)
+    if rank == 0:
+        print(json.dumps({"launcher": "launch_stage2", "world_size": world, "steps": int(trainer.total_steps), "exchange": "mean all-reduce of %d gradients in %d bucket(s)"
+                          % (sum(p.numel() for p in reducer.params), len(reducer.buckets)), "backend": dist.get_backend() if dist.is_initialized() else None}))
+    D.shutdown()
+
+
+if __name__ == "__main__":
+    main()
