@@ -677,3 +677,67 @@ def test_fov_clamp_rotated_camera_nonunit_quaternions_scale_modifier(cfg, family
         e = _norm_err(grads[k], og[k])
         assert e[~touched].max() <= _max_tol(family, k), "%s: %.3e" % (k, e[~touched].max())
         assert np.abs(grads[k][oradii == 0]).max(initial=0.0) == 0.0
+
+
+def test_fused_scan_with_eight_concurrent_streams_and_a_chip_filling_kernel(monkeypatch):
+    """The one-launch bin scan spin-waits on its sibling workgroups (gsr_binning.hip, k_scan_b<true>), which is safe only while all of
+    them get a slot.  Stress: eight forward+backward pairs in flight at once on eight streams (GPSGS_CHECK=deferred: no host wait
+    between them) while another stream keeps every CU busy with long-running filler kernels (what an RCCL all-reduce or the networks'
+    kernels of stage 2 look like to the dispatcher).  Must finish (the whole test runs under a watchdog) and reproduce the serial
+    results bit for bit."""
+    import threading
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    dev = torch.device("cuda:0")
+    scenes = [S.make_scene(256, 30000), S.make_uniform_cloud(20000, 333, 277, seed=3, scale_med=0.02), S.make_scene(256, 30000, render_res=512),
+              S.make_uniform_cloud(6000, 200, 120, seed=5, scale_med=0.05)]
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+
+    def prepare(g):
+        t = {k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32)).to(dev).requires_grad_(True) for k in names}
+        rs = RZ.GaussianRasterizationSettings(g["H"], g["W"], g["tanfovx"], g["tanfovy"], torch.from_numpy(g["bg"]).to(dev), 1.0,
+                                              torch.from_numpy(g["view"]).to(dev), torch.from_numpy(g["proj"]).to(dev), 3,
+                                              torch.from_numpy(g["campos"]).to(dev), False, False)
+        gout = torch.randn(3, g["H"], g["W"], device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        return t, RZ.GaussianRasterizer(rs), gout
+
+    def run(p):
+        t, rast, gout = p
+        m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+        img, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
+        grads = torch.autograd.grad(img, [t[k] for k in names], gout)
+        return img.detach(), grads
+
+    prepared = [prepare(g) for g in scenes] * 2            # eight work items
+    serial = [run(p) for p in prepared]                    # sync mode, one after the other: the reference results (and the learnt capacity)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("GPSGS_CHECK", "deferred")
+    streams = [torch.cuda.Stream() for _ in prepared]
+    filler_stream = torch.cuda.Stream()
+    big = torch.rand(64 << 20, device=dev)                 # 256 MB: tens of thousands of workgroups per filler kernel
+    done = threading.Event()
+    watchdog = threading.Timer(120.0, lambda: (done.is_set() or os._exit(3)))   # a hang must not take the whole session down
+    watchdog.start()
+    try:
+        for rep in range(3):
+            with torch.cuda.stream(filler_stream):
+                y = big
+                for _ in range(12):
+                    y = torch.sin(y) * 1.0001 + 0.1        # long-running, fills all 256 CUs
+            out = []
+            for p, s in zip(prepared, streams):
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    out.append(run(p))
+            torch.cuda.synchronize()
+            for (img, grads), (img0, grads0) in zip(out, serial):
+                assert torch.equal(img, img0)
+                for a, b in zip(grads, grads0):
+                    assert torch.equal(a, b)
+    finally:
+        done.set()
+        watchdog.cancel()
+    monkeypatch.setenv("GPSGS_CHECK", "sync")
+    run(prepared[0])                                       # drains the deferred headers: none of them may report an overflow
+    torch.cuda.synchronize()
