@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--res", type=int, default=1024, help="source resolution (config 2: 1024)")
     ap.add_argument("--render-res", type=int, default=None, help="render resolution (default = --res)")
     ap.add_argument("--gaussians", type=int, default=600_000)
+    ap.add_argument("--inflight", type=int, default=6, help="independent views rendered concurrently per GPU (one RasterSession + HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-leg", action="store_true", help="(internal) time HIP-graph replays of the fwd+bwd step and print one JSON line")
     args = ap.parse_args()
@@ -213,29 +214,64 @@ def main():
 
     # ---- the headline step: forward + backward of one view through the C-ABI (gsr_forward_notify + gsr_backward), driven by
     # gps_gaussian_amd.session.RasterSession: same kernels, same exact capacity check (the scan publishes the instance count to pinned
-    # host memory, the host waits for it every forward, an overflow would be re-rendered), preallocated buffers, no autograd round trip
+    # host memory, the host waits for it every forward, an overflow would be re-rendered), preallocated buffers, no autograd round trip.
+    # Views are independent units, and one view's kernels leave the chip under-occupied (config 2 has ~5 one-wave compositing work
+    # items per SIMD): --inflight F views are rendered CONCURRENTLY, each by its own session on its own HIP stream.  A "step" is still
+    # one view (forward + backward); steps are issued in groups of F (begin all forwards, then per view: capacity check + backward).
     from gps_gaussian_amd.session import RasterSession
-    sess = RasterSession(P, W, H, dev, training=True)
+    F = max(1, args.inflight)
     raw = {k: t[k].detach() for k in names}
-    opa_flat = raw["opacities"].reshape(-1)
+    lanes = [dict(sess=RasterSession(P, W, H, dev, training=True), stream=torch.cuda.Stream(device=dev), m3=raw["means3D"], col=raw["colors"],
+                  opa=raw["opacities"].reshape(-1), sca=raw["scales"], rot=raw["rotations"], view=rs.viewmatrix, proj=rs.projmatrix, gout=gout)]
+    for i in range(1, F):  # further views of the same rig (different novel pose and stereo pair), same size
+        si = S.make_stereo_sample(args.res, args.gaussians, seed=S.SEED + rank + 1000 * i, render_res=render_res)
+        gi, ci = S.compact_sample(si), si["novel_view"]
+        assert gi["means3D"].shape[0] == P
+        ti = {k: torch.from_numpy(gi[k]).to(dev) for k in names}
+        lanes.append(dict(sess=RasterSession(P, W, H, dev, training=True), stream=torch.cuda.Stream(device=dev), m3=ti["means3D"], col=ti["colors"],
+                          opa=ti["opacities"].reshape(-1), sca=ti["scales"], rot=ti["rotations"], view=torch.from_numpy(ci["world_view_transform"]).to(dev),
+                          proj=torch.from_numpy(ci["full_proj_transform"]).to(dev), gout=torch.randn(3, H, W, device=dev)))
+    torch.cuda.synchronize(dev)
 
-    def step():
-        sess.forward(raw["means3D"], raw["colors"], opa_flat, raw["scales"], raw["rotations"], rs.viewmatrix, rs.projmatrix, rs.bg,
-                     rs.tanfovx, rs.tanfovy, 1.0)
-        sess.backward(gout)
+    def group(n):  # n <= F views, concurrently
+        for L in lanes[:n]:
+            with torch.cuda.stream(L["stream"]):
+                L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
+        for L in lanes[:n]:
+            with torch.cuda.stream(L["stream"]):
+                L["sess"].forward_end()
+                L["sess"].backward(L["gout"])
+
+    def steps_pipelined(k):
+        while k > 0:
+            group(min(F, k))
+            k -= min(F, k)
+
+    sess = lanes[0]["sess"]
+
+    def step():  # one view at a time on the current stream (calibration of the per-kernel table, and the single-view-in-flight number)
+        L = lanes[0]
+        sess.forward(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
+        sess.backward(L["gout"])
 
     def barrier():
         D.barrier(local_rank)
 
-    def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
+    def timed(fn, steps, warmup, multi=False):  # multi: fn(k) runs k steps itself (pipelined groups)
+        if multi:
+            fn(warmup)
+        else:
+            for _ in range(warmup):
+                fn()
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
+        if multi:
+            fn(steps)
+        else:
+            for _ in range(steps):
+                fn()
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
@@ -256,16 +292,18 @@ def main():
     # not perturb the pipeline it measures.  After the switch to that final mode >= 10 untimed steps run before anything is timed.
     # Then REPEATS blocks of EXACTLY --steps steps each are timed (barrier + synchronize on both sides, MAX over ranks); `value`,
     # `ms_per_step` are those of the MEDIAN block (all blocks are listed in `repeats_ms_per_step`). ------------------------------------
+    serial_dom_us = stages[dom_stage][0] / max(1, stages[dom_stage][1]) * 1e3  # one view at a time (calibration pass above)
     RZ.set_stage_timing(True, dom_stage)
-    for _ in range(max(10, args.warmup)):
-        step()
+    steps_pipelined(max(10, args.warmup, 2 * F) + 4 * F)  # also lets the clocks settle under the concurrent load
     torch.cuda.synchronize(dev)
     _capi.timing_read()
     REPEATS = 5
-    blocks = [timed(step, args.steps, 0) for _ in range(REPEATS)]
+    blocks = [timed(steps_pipelined, args.steps, 0, multi=True) for _ in range(REPEATS)]
     dom_live = _capi.timing_read()[dom_stage]
     RZ.set_stage_timing(False)
-    stages[dom_stage] = dom_live  # the roofline uses the duration measured inside the timed region
+    # the roofline uses the duration measured inside the timed region (F launches overlapping: they time-share the chip, so each launch
+    # lasts longer than it does alone while the aggregate rate is higher); the `stages` table lists the one-view-at-a-time durations
+    el_single = timed(step, args.steps, 5)  # secondary: one view in flight
     elapsed = sorted(blocks)[REPEATS // 2]
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
@@ -336,7 +374,8 @@ def main():
                     pmc_src = pj.get("source")
             except Exception:  # noqa: BLE001
                 traffic = None
-        dom_us = per_stage[dom]["avg_us"]
+        dom_us = round(dom_live[0] / max(1, dom_live[1]) * 1e3, 2) if dom == dom_stage and dom_live[1] else per_stage[dom]["avg_us"]
+        achieved = round(alg_bytes[dom] / (dom_us * 1e-6) / 1e9, 1)
         alg_tile = None
         if R_tile and dom in ("composite_fwd", "composite_bwd"):  # the same formula with SURVEY's 16x16-tile instance count (T = 16x16 tiles)
             T16 = ((W + 15) // 16) * ((H + 15) // 16)
@@ -344,6 +383,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_src,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": dom_us,
+                    "views_in_flight": F, "avg_launch_us_one_view_in_flight": round(serial_dom_us, 2),
+                    "frac_one_view_in_flight": round(alg_bytes[dom] / (serial_dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "instances": {"bin_8x8": R, "tile_16x16": R_tile},
                     "frac_with_tile_16x16_instances": (round(alg_tile / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if alg_tile else None),
                     # compositing is FP32-VALU bound, not HBM bound: one wave64 VALU instruction holds a SIMD for 4 cycles;
@@ -419,8 +460,11 @@ def main():
                                    "HIP rasteriser forward+backward, one view per step per GPU" % (W, H, P, R),
                        "host": "C-ABI (gsr_forward_notify + gsr_backward) driven by gps_gaussian_amd.session.RasterSession: preallocated buffers, no "
                                "autograd round trip; the same step through the drop-in autograd module is `autograd_api_views_per_s`",
+                       "views_in_flight": "%d independent views per GPU rendered concurrently (one session + HIP stream each); one at a time: "
+                                          "`single_view_in_flight_views_per_s`" % F,
                        "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)"},
             "repeats_ms_per_step": [round(x / args.steps * 1e3, 4) for x in blocks],
+            "single_view_in_flight_views_per_s": round(world * args.steps / el_single, 2),
             "autograd_api_views_per_s": round(world * args.steps / el_api, 2),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
             "forward_only_views_per_s": round(world * args.steps / el_fwd, 2),

@@ -31,7 +31,7 @@ class RasterSession:
         self.color = torch.empty((3, self.H, self.W), dtype=f32, device=d)
         self.radii = torch.empty((self.P,), dtype=torch.int32, device=d)
         self.ws, self.cap, self.nbytes = None, 0, 0
-        self._in = None
+        self._in, self._pending, self._cur = None, None, None
         if self.training:
             # one buffer, six contiguous gradient arrays carved out of it
             P_ = max(self.P, 1)
@@ -57,40 +57,61 @@ class RasterSession:
 
     def forward(self, means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg, tanfovx, tanfovy, scale_modifier=1.0):
         """-> (color[3,H,W], radii[P]) (the session's own buffers: valid until the next forward).  Enqueues on the current stream."""
+        self.forward_begin(means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg, tanfovx, tanfovy, scale_modifier)
+        return self.forward_end()
+
+    def forward_begin(self, means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg, tanfovx, tanfovy, scale_modifier=1.0):
+        """First half of forward(): enqueue the forward kernels on the current stream and return at once.  forward_end() then waits for
+        the capacity notification (and repairs an overflow).  Several sessions on several streams can so be started back to back --
+        independent views rendered concurrently -- before the host waits for any of them."""
         P, W, H, lib = self.P, self.W, self.H, self.lib
         ptrs = (self._chk(means3D, 3 * P, "means3D"), self._chk(colors, 3 * P, "colors"), self._chk(opacities, P, "opacities"),
                 self._chk(scales, 3 * P, "scales"), self._chk(rotations, 4 * P, "rotations"))
         cam = (self._chk(viewmatrix, 16, "viewmatrix"), self._chk(projmatrix, 16, "projmatrix"), self._chk(bg, 3, "bg"))
         fl = (float(scale_modifier), float(tanfovx), float(tanfovy))
-        st = RZ._dev_state(self.dev)
-        cur = torch.cuda.current_stream(self.dev)
-        stream = cur.cuda_stream
-        ring = RZ._ring(self.dev)
         family = RZ._composite_flag()
+        self._in = (ptrs, fl, cam, family, (means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg))  # keeps the inputs alive
+        st = RZ._dev_state(self.dev)
+        self._cur = torch.cuda.current_stream(self.dev)
+        self._enqueue(max(self.cap, RZ._capacity_for(st, P)))
+
+    def _enqueue(self, cap):
+        P, W, H, lib = self.P, self.W, self.H, self.lib
+        ptrs, fl, cam, family, _ = self._in
+        st = RZ._dev_state(self.dev)
+        stream = self._cur.cuda_stream
         flags = RZ._extra_flags | family
-        cap = max(self.cap, RZ._capacity_for(st, P))
-        while True:
-            self._ensure_ws(cap)
-            if P == 0:
-                _capi.check(lib.gsr_forward(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
-                                            self.nbytes, cap, flags, stream), "gsr_forward")
-                break
-            hdr, w32, hdr_ptr, seq = ring.next_notify()
-            skip_large = not st.get("big_bins", False)
-            f = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
-            _capi.check(lib.gsr_forward_notify(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
-                                               self.nbytes, cap, f, stream, hdr_ptr, seq), "gsr_forward_notify")
-            RZ._wait_notify(w32, seq, cur)
+        self._ensure_ws(cap)
+        if P == 0:
+            _capi.check(lib.gsr_forward(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
+                                        self.nbytes, cap, flags, stream), "gsr_forward")
+            self._pending = None
+            return
+        hdr, w32, hdr_ptr, seq = RZ._ring(self.dev).next_notify()
+        skip_large = not st.get("big_bins", False)
+        f = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
+        _capi.check(lib.gsr_forward_notify(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
+                                           self.nbytes, cap, f, stream, hdr_ptr, seq), "gsr_forward_notify")
+        self._pending = (hdr, w32, seq)
+
+    def forward_end(self):
+        """Second half of forward(): wait until the binning scan has published the instance count (typically well before the forward has
+        finished), re-render with a larger workspace if it overflowed.  -> (color, radii)"""
+        st = RZ._dev_state(self.dev)
+        while self._pending is not None:
+            hdr, w32, seq = self._pending
+            RZ._wait_notify(w32, seq, self._cur)
             R, overflow, need = RZ._decode(hdr)
-            RZ._learn(st, R, need, P)
+            RZ._learn(st, R, need, self.P)
             if int(w32[3]) > 768:
                 st["big_bins"] = True
             if not overflow:
+                self._pending = None
                 break
-            if cap >= 0x7fffffff:
+            if self.cap >= 0x7fffffff:
                 raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace layout can address" % R)
-            cap = RZ._capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
-        self._in = (ptrs, fl, cam, family, (means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg))  # keeps the inputs alive
+            with torch.cuda.stream(self._cur):
+                self._enqueue(RZ._capacity_for(st, self.P))  # the in-flight kernels of the failed attempt exit at once on the overflow flag
         return self.color, self.radii
 
     def backward(self, dL_dpix):
