@@ -173,6 +173,30 @@ def _wait_notify(w32, seq, cur_stream):
             raise RuntimeError("gps_gaussian_amd: the rasteriser forward finished without publishing its header")
 
 
+# ---- several forwards in flight (pts2render: one stream per sample of the batch) ---------------------------------------------------
+_deferred = None  # list collecting the capacity checks of forwards enqueued inside `defer_capacity_checks()`
+
+
+class defer_capacity_checks:
+    """Context: sync-mode forwards enqueued inside it do not wait for their capacity notification one by one; all of them are checked
+    (and, on overflow, re-rendered in place) when the context exits.  Lets a caller enqueue independent views on several streams back
+    to back so that they run concurrently, with the same exactness guarantee as the blocking form.  Their images must not be consumed
+    before the context has exited."""
+
+    def __enter__(self):
+        global _deferred
+        self.prev, _deferred = _deferred, []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _deferred
+        todo, _deferred = _deferred, self.prev
+        if et is None:
+            for finish in todo:
+                finish()
+        return False
+
+
 _rings = {}
 
 
@@ -290,6 +314,37 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
                                                 stream, hdr_ptr, seq)
                     _capi.check(rc, "gsr_forward_notify")
+                    if _deferred is not None:
+                        # checked when the enclosing defer_capacity_checks() exits (several views in flight); an overflow is repaired
+                        # there, in place: same output tensors, a larger workspace in ctx.ws_box
+                        box = [ws, cap]
+                        ctx.ws_box = box
+
+                        def finish(hdr=hdr, w32=w32, seq=seq, flags=flags):
+                            while True:
+                                _wait_notify(w32, seq, cur_stream)
+                                R, overflow, need = _decode(hdr)
+                                _learn(st, R, need, P)
+                                if int(w32[3]) > 768:
+                                    st["big_bins"] = True
+                                if not overflow:
+                                    return
+                                if box[1] >= 0x7fffffff:
+                                    raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the "
+                                                       "workspace layout can address" % R)
+                                with torch.cuda.stream(cur_stream):
+                                    box[1] = _capacity_for(st, P)
+                                    nb = ws_bytes(P, W, H, box[1])
+                                    box[0] = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                                    hdr, w32, hdr_ptr2, seq = ring.next_notify()
+                                    fl = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (0 if st.get("big_bins", False) else _capi.GSR_FLAG_NO_LARGE_SORT)
+                                    _capi.check(lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
+                                                                       float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
+                                                                       _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(box[0]), nb, box[1], fl,
+                                                                       cur_stream.cuda_stream, hdr_ptr2, seq), "gsr_forward_notify")
+
+                        _deferred.append(finish)
+                        break
                     _wait_notify(w32, seq, cur_stream)
                     R, overflow, need = _decode(hdr)
                     _learn(st, R, need, P)
@@ -341,6 +396,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         lib = _capi.lib()
         m3, col, opa, sca, rot, view, proj, bg, radii, ws = ctx.saved_tensors
+        cap = ctx.cap
+        box = getattr(ctx, "ws_box", None)
+        if box is not None:  # forward ran inside defer_capacity_checks(): the workspace may have been replaced by the overflow repair
+            ws, cap = box
         dev = m3.device
         P = m3.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
@@ -368,7 +427,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                       float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
                                       _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
-                                      ws.numel(), ctx.cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | ctx.family, stream)
+                                      ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | ctx.family, stream)
                 _capi.check(rc, "gsr_backward")
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
         return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None, None

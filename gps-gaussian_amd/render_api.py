@@ -10,7 +10,17 @@ import math
 
 import torch
 
+from . import rasterizer as _RZ
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+_stream_pool = {}  # device index -> side streams: the samples of a batch are independent views and render concurrently
+
+
+def _streams(dev, n):
+    pool = _stream_pool.setdefault(dev.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
 
 
 def _scalar(x):
@@ -93,11 +103,26 @@ def pts2render(data, bg_color):
         arenas, a_parts = [None] * 5, None
     parts = [_SplitRows.apply(t, sizes, a) for t, a in zip(packed, arenas)]
     out = []
+    dev = xyz.device
+    cur = torch.cuda.current_stream(dev)
+    # One view's kernels leave the chip under-occupied (~5 one-wave compositing work items per SIMD at 1024^2 / 600k Gaussians), and the
+    # samples of a batch are independent: each is enqueued on its own HIP stream so that they render concurrently (the reference loops
+    # over them on one stream, lib/GaussianRender.py:9).  Their capacity checks are collected and run after all of them are in flight;
+    # autograd runs every sample's backward on the stream of its forward, so the backward passes overlap the same way.
+    side = _streams(dev, bs) if (bs > 1 and not torch.cuda.is_current_stream_capturing()) else [cur] * bs
+    with _RZ.defer_capacity_checks():
+        for i in range(bs):
+            # arena order expected by the rasteriser: means3D, colours, opacities, scales, rotations
+            ga = (a_parts[0][i], a_parts[1][i], a_parts[4][i], a_parts[3][i], a_parts[2][i]) if a_parts is not None else None
+            if side[i] is not cur:
+                side[i].wait_stream(cur)
+            with torch.cuda.stream(side[i]):
+                out.append(render(data, i, parts[0][i], parts[1][i], parts[2][i], parts[3][i], parts[4][i], bg_color=bg_color,
+                                  grad_arena=ga).unsqueeze(0))
     for i in range(bs):
-        # arena order expected by the rasteriser: means3D, colours, opacities, scales, rotations
-        ga = (a_parts[0][i], a_parts[1][i], a_parts[4][i], a_parts[3][i], a_parts[2][i]) if a_parts is not None else None
-        out.append(render(data, i, parts[0][i], parts[1][i], parts[2][i], parts[3][i], parts[4][i], bg_color=bg_color,
-                          grad_arena=ga).unsqueeze(0))
+        if side[i] is not cur:
+            cur.wait_stream(side[i])
+            out[i].record_stream(cur)
     data['novel_view']['img_pred'] = torch.cat(out, dim=0)
     return data
 

@@ -741,3 +741,48 @@ def test_fused_scan_with_eight_concurrent_streams_and_a_chip_filling_kernel(monk
     monkeypatch.setenv("GPSGS_CHECK", "sync")
     run(prepared[0])                                       # drains the deferred headers: none of them may report an overflow
     torch.cuda.synchronize()
+
+
+def test_deferred_capacity_checks_with_views_in_flight_on_several_streams(monkeypatch):
+    """rasterizer.defer_capacity_checks() (what pts2render uses to render the samples of a batch concurrently): forwards enqueued inside
+    it return without waiting; on exit every one is checked and an overflow is repaired in place (same image tensor, new workspace for
+    the backward).  Results must equal the blocking form bit for bit, with and without overflows."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    dev = torch.device("cuda:0")
+    scenes = [S.make_uniform_cloud(5000, 128, 96, seed=9, scale_med=0.05), S.make_scene(256, 30000), S.make_uniform_cloud(3000, 96, 80, seed=5, scale_med=0.08)]
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    ref = []
+    for g in scenes:
+        dpix = np.random.default_rng(1).standard_normal((3, g["H"], g["W"])).astype(np.float32)
+        ref.append((dpix,) + hip_render(g, dpix)[:3])
+    real = RZ._capacity_for
+    for tiny in (False, True):
+        calls = []
+        monkeypatch.setattr(RZ, "_capacity_for", (lambda st, P: (calls.append(1), 1500 if len(calls) <= len(scenes) else real(st, P))[1]) if tiny else real)
+        streams = [torch.cuda.Stream() for _ in scenes]
+        imgs, leaves = [], []
+        with RZ.defer_capacity_checks():
+            for g, s in zip(scenes, streams):
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    t = {k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32)).to(dev).requires_grad_(True) for k in names}
+                    m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+                    rs = RZ.GaussianRasterizationSettings(g["H"], g["W"], g["tanfovx"], g["tanfovy"], torch.from_numpy(g["bg"]).to(dev), 1.0,
+                                                          torch.from_numpy(g["view"]).to(dev), torch.from_numpy(g["proj"]).to(dev), 3,
+                                                          torch.from_numpy(g["campos"]).to(dev), False, False)
+                    img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"],
+                                                           scales=t["scales"], rotations=t["rotations"])
+                    imgs.append((img, radii)); leaves.append((t, m2))
+        assert (len(calls) > len(scenes)) == tiny          # the overflows were seen and repaired on exit
+        for (img, radii), (t, m2), (dpix, rimg, rradii, rgrads), s in zip(imgs, leaves, ref, streams):
+            with torch.cuda.stream(s):
+                img.backward(torch.from_numpy(dpix).to(dev))
+            s.synchronize()
+            np.testing.assert_array_equal(img.detach().cpu().numpy(), rimg)
+            np.testing.assert_array_equal(radii.cpu().numpy(), rradii)
+            for k in names:
+                np.testing.assert_array_equal(t[k].grad.cpu().numpy(), rgrads[k])
+            np.testing.assert_array_equal(m2.grad.cpu().numpy(), rgrads["means2D"])
+    monkeypatch.setattr(RZ, "_capacity_for", real)
