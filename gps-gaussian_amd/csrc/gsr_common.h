@@ -136,7 +136,16 @@ __device__ __forceinline__ GsrHit gsr_hit_setup(float x, float y, float A, float
     h.rC = 1.f / C;
     return h;
 }
-// minimum of the quadratic form over the rectangle of pixel centres [X0, X1] x [Y0, Y1] against the (inflated) threshold
+// minimum of the quadratic form over the rectangle of pixel centres [X0, X1] x [Y0, Y1] against the (inflated) threshold.
+// The fixed inflation of the threshold (0.2 % + 0.02) covers the difference between this evaluation order and the compositing
+// kernels' exp(); what it cannot cover is the rounding of q itself when the conic is strongly anisotropic or correlated and the terms
+// A dx^2, 2 B dx dy, C dy^2 are far larger than their sum: every candidate is therefore credited 1e-5 of the sum of the terms'
+// MAGNITUDES (fp32 evaluates q to a few 1e-7 of that sum), so a pair the compositor could still blend is never dropped.
+__device__ __forceinline__ float gsr_q_lower(const GsrHit &h, float dx, float dy) {
+    _Pragma("clang fp contract(off)")
+    const float a = h.A * dx * dx, b = 2.f * h.B * dx * dy, c = h.C * dy * dy;
+    return (a + b + c) - 1e-5f * (fabsf(a) + fabsf(b) + fabsf(c));
+}
 __device__ __forceinline__ bool gsr_rect_hit(const GsrHit &h, float X0, float X1, float Y0, float Y1) {
     _Pragma("clang fp contract(off)")
     const float cx = fminf(fmaxf(h.x, X0), X1), cy = fminf(fmaxf(h.y, Y0), Y1);
@@ -145,14 +154,12 @@ __device__ __forceinline__ bool gsr_rect_hit(const GsrHit &h, float X0, float X1
     if (cx != h.x) {  // vertical edge x = cx faces the centre
         const float dx = cx - h.x;
         const float yy = fminf(fmaxf(h.y - h.B * dx * h.rC, Y0), Y1);
-        const float dy = yy - h.y;
-        best = fminf(best, h.A * dx * dx + 2.f * h.B * dx * dy + h.C * dy * dy);
+        best = fminf(best, gsr_q_lower(h, dx, yy - h.y));
     }
     if (cy != h.y) {  // horizontal edge y = cy faces the centre
         const float dy = cy - h.y;
         const float xx = fminf(fmaxf(h.x - h.B * dy * h.rA, X0), X1);
-        const float dx = xx - h.x;
-        best = fminf(best, h.A * dx * dx + 2.f * h.B * dx * dy + h.C * dy * dy);
+        best = fminf(best, gsr_q_lower(h, xx - h.x, dy));
     }
     return best <= h.thr;
 }

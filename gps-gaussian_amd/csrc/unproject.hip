@@ -88,12 +88,17 @@ bool fill(UnprojArgs &a, int B, int S, const float *ref_intr, const float *intr,
 extern "C" int up_unproject_forward(int B, int S, const float *flow, const float *mask, int64_t mask_batch_stride, const float *ref_intr_host,
                                     const float *intr_host, const float *extr_host, const float *tf_host, float *depth, float *xyz,
                                     uint8_t *valid, void *stream) {
-    UnprojArgs a;
-    if (!ref_intr_host || !intr_host || !extr_host || !tf_host || !fill(a, B, S, ref_intr_host, intr_host, extr_host, tf_host)) return GPSGS_E_INVALID;
+    if (B < 0 || S < 0 || !ref_intr_host || !intr_host || !extr_host || !tf_host) return GPSGS_E_INVALID;
     if (B == 0 || S == 0) return GPSGS_OK;
     if (!flow || !mask || !depth || !xyz || !valid) return GPSGS_E_INVALID;
-    hipLaunchKernelGGL(k_unproject_fwd, dim3((S * S + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a, flow, mask, mask_batch_stride, depth,
-                       xyz, valid);
+    const size_t S2 = (size_t)S * S;
+    for (int b0 = 0; b0 < B; b0 += MAXB) {  // the cameras travel by value in the kernel arguments, MAXB at a time: any batch size works
+        const int nb = B - b0 < MAXB ? B - b0 : MAXB;
+        UnprojArgs a;
+        if (!fill(a, nb, S, ref_intr_host + 9 * b0, intr_host + 9 * b0, extr_host + 12 * b0, tf_host + b0)) return GPSGS_E_INVALID;
+        hipLaunchKernelGGL(k_unproject_fwd, dim3((S * S + 255) / 256, nb), dim3(256), 0, (hipStream_t)stream, a, flow + b0 * S2,
+                           mask + (int64_t)b0 * mask_batch_stride, mask_batch_stride, depth + b0 * S2, xyz + b0 * S2 * 3, valid + b0 * S2);
+    }
     return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
 }
 
@@ -101,11 +106,18 @@ extern "C" int up_unproject_backward(int B, int S, const float *depth, const flo
                                      const float *intr_host, const float *extr_host, const float *tf_host, const float *g_depth,
                                      const float *g_xyz, int64_t gx_batch_stride, int64_t gx_pixel_stride, int64_t gx_channel_stride,
                                      float *d_flow, void *stream) {
-    UnprojArgs a;
-    if (!ref_intr_host || !intr_host || !extr_host || !tf_host || !fill(a, B, S, ref_intr_host, intr_host, extr_host, tf_host)) return GPSGS_E_INVALID;
+    if (B < 0 || S < 0 || !ref_intr_host || !intr_host || !extr_host || !tf_host) return GPSGS_E_INVALID;
     if (B == 0 || S == 0) return GPSGS_OK;
     if (!depth || !mask || !d_flow) return GPSGS_E_INVALID;
-    hipLaunchKernelGGL(k_unproject_bwd, dim3((S * S + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a, depth, mask, mask_batch_stride, g_depth,
-                       g_xyz, gx_batch_stride, gx_pixel_stride, gx_channel_stride, d_flow);
+    const size_t S2 = (size_t)S * S;
+    for (int b0 = 0; b0 < B; b0 += MAXB) {
+        const int nb = B - b0 < MAXB ? B - b0 : MAXB;
+        UnprojArgs a;
+        if (!fill(a, nb, S, ref_intr_host + 9 * b0, intr_host + 9 * b0, extr_host + 12 * b0, tf_host + b0)) return GPSGS_E_INVALID;
+        hipLaunchKernelGGL(k_unproject_bwd, dim3((S * S + 255) / 256, nb), dim3(256), 0, (hipStream_t)stream, a, depth + b0 * S2,
+                           mask + (int64_t)b0 * mask_batch_stride, mask_batch_stride, g_depth ? g_depth + b0 * S2 : nullptr,
+                           g_xyz ? g_xyz + (int64_t)b0 * gx_batch_stride : nullptr, gx_batch_stride, gx_pixel_stride, gx_channel_stride,
+                           d_flow + b0 * S2);
+    }
     return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
 }

@@ -200,10 +200,13 @@ class defer_capacity_checks:
 _rings = {}
 
 
-def _ring(dev):
-    r = _rings.get(dev.index)
+def _ring(dev, kind="notify"):
+    """Pinned header slots of a device.  Two rings: "notify" (slots the scan kernel writes directly, reused as soon as the host has seen
+    the sequence word) and "copy" (targets of header copies that may stay pending across calls in deferred mode) -- a slot of one
+    kind can so never be handed out while the other path still has it in flight."""
+    r = _rings.get((dev.index, kind))
     if r is None:
-        r = _rings[dev.index] = _HeaderRing()
+        r = _rings[(dev.index, kind)] = _HeaderRing()
     return r
 
 
@@ -364,9 +367,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _capi.check(rc, "gsr_forward")
                 if P == 0 or mode == "none":
                     break
-                if mode == "deferred" and len(st["pending"]) >= ring.n - 1:
+                cring = _ring(dev, "copy")
+                if mode == "deferred" and len(st["pending"]) >= cring.n - 1:
                     _drain_pending(st, block=True)  # never reuse a pinned slot that is still in flight
-                hdr, hdr_ptr, ev = ring.next()
+                hdr, hdr_ptr, ev = cring.next()
                 _capi.check(lib.gsr_copy_header_async(_ptr(ws), hdr_ptr, stream), "gsr_copy_header_async")
                 ev.record(cur_stream)
                 if mode == "deferred":

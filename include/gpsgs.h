@@ -182,7 +182,7 @@ int fl_l1_ssim_backward(const float *pred, const float *gt, const float *m1, con
 
 /* ---- fused disparity -> inverse depth -> world points (lib/utils.py:88-120, lib/network.py:66-69) ---------------------
  * flow [B,1,S,S], mask channel 0 of [B,C,S,S] (mask_batch_stride = C*S*S elements), camera parameters on the HOST:
- * ref_intr/intr [B,3,3], extr [B,3,4] row-major, Tf_x [B]; B <= 16.  Outputs depth [B,1,S,S] (inverse depth), xyz [B,S*S,3],
+ * ref_intr/intr [B,3,3], extr [B,3,4] row-major, Tf_x [B] (any B: launched 16 samples at a time).  Outputs depth [B,1,S,S] (inverse depth), xyz [B,S*S,3],
  * valid [B,S*S] (u8).  Backward: g_depth [B,1,S,S] and/or g_xyz (element strides given; either may be NULL) -> d_flow. */
 int up_unproject_forward(int B, int S, const float *flow, const float *mask, int64_t mask_batch_stride, const float *ref_intr_host,
                          const float *intr_host, const float *extr_host, const float *tf_host, float *depth, float *xyz,

@@ -786,3 +786,59 @@ def test_deferred_capacity_checks_with_views_in_flight_on_several_streams(monkey
                 np.testing.assert_array_equal(t[k].grad.cpu().numpy(), rgrads[k])
             np.testing.assert_array_equal(m2.grad.cpu().numpy(), rgrads["means2D"])
     monkeypatch.setattr(RZ, "_capacity_for", real)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_exact_bin_culling_is_sound_for_needle_shaped_splats(seed):
+    """Strongly anisotropic, arbitrarily rotated Gaussians (axis ratio up to ~3000:1): the conic's quadratic form then cancels heavily
+    (|A dx^2| + |2 B dx dy| + |C dy^2| >> q), which is where a fixed margin in the exact (Gaussian, bin) cull could drop a pair the
+    compositor would still blend.  Checked directly on the lists the forward built (not through the image: with such conics any two
+    fp32 evaluation orders of the exponent differ by more than the image tolerance): every (Gaussian, 8x8 bin) pair inside upstream's
+    tile rect that is NOT listed must have alpha < 1/255 at all 64 pixel centres of the bin, evaluated in fp64 from the same fp32
+    conic / centre / opacity; and nothing outside the tile rect may be listed."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    W, H, P = 160, 120, 4000
+    g = S.make_uniform_cloud(P, W, H, seed=seed, scale_med=0.02, z_range=(0.5, 4.0), behind_frac=0.0)
+    rng = np.random.default_rng(seed)
+    g["scales"][:, 0] *= rng.uniform(5, 60, P).astype(np.float32)
+    g["scales"][:, 1:] /= rng.uniform(5, 50, (P, 1)).astype(np.float32)
+    g["opacities"] = np.clip(g["opacities"], 0.02, 0.9).astype(np.float32)
+    img, radii, _, info = hip_render(g, np.zeros((3, H, W), np.float32))
+    o, _, oradii = oracle_render(g, "f32")
+    np.testing.assert_array_equal(radii, oradii)
+    geom = o.geom()
+    st = RZ.export_state(info["ws"], P, W, H, info["cap"])
+    ranges, plist, bxp = st["ranges"].cpu().numpy(), st["point_list"].cpu().numpy().astype(np.int64), st["bx"]
+    listed = set()
+    for b, (a_, b_) in enumerate(ranges):
+        for i in plist[a_:b_]:
+            listed.add((b, int(i)))
+    uu, vv = np.meshgrid(np.arange(8.0), np.arange(8.0))
+    checked = dropped = 0
+    worst = 0.0
+    cond = []
+    for i in np.nonzero(oradii > 0)[0]:
+        x, y = geom["xy"][i].astype(np.float64)
+        A, B, C, op = geom["conic_opacity"][i].astype(np.float64)
+        cond.append((A + C) ** 2 / max(A * C - B * B, 1e-300))
+        tx0, ty0, tx1, ty1 = geom["rect"][i]
+        for by_ in range(2 * ty0, min(2 * ty1, (H + 7) // 8)):
+            for bx_ in range(2 * tx0, min(2 * tx1, (W + 7) // 8)):
+                checked += 1
+                if (by_ * bxp + bx_, int(i)) in listed:
+                    continue
+                dx, dy = x - (8 * bx_ + uu), y - (8 * by_ + vv)
+                inside = (8 * bx_ + uu < W) & (8 * by_ + vv < H)
+                alpha = np.where(inside, np.minimum(0.99, op * np.exp(-0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy)), 0.0)
+                dropped += 1
+                worst = max(worst, float(alpha.max()))
+    for (b, i) in listed:                                   # nothing is ever added outside upstream's tile rect
+        by_, bx_ = divmod(b, bxp)
+        tx0, ty0, tx1, ty1 = geom["rect"][i]
+        assert 2 * tx0 <= bx_ < 2 * tx1 and 2 * ty0 <= by_ < 2 * ty1
+    print("needles[seed %d]: %d (Gaussian, bin) pairs in the tile rects, %d culled, largest alpha among the culled %.6f (1/255 = %.6f), "
+          "conic condition numbers up to %.1e" % (seed, checked, dropped, worst, 1 / 255, max(cond)))
+    assert dropped > checked // 4 and max(cond) > 1e4
+    assert worst < 1.0 / 255.0

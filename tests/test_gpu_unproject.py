@@ -51,3 +51,26 @@ def test_feeds_the_pack_and_raster_path():
     assert offs[-1] == 2 * int(g["valid"].sum())
     n0 = int(g["valid"][0].sum())
     np.testing.assert_array_equal(out[0][:n0].cpu().numpy(), data["lmain"]["xyz"][0][data["lmain"]["pts_valid"][0]].cpu().numpy())
+
+
+def test_batches_larger_than_one_launch_chunk():
+    """The cameras travel by value in the kernel arguments, 16 samples per launch; a batch of 37 (the fixture's samples tiled) must give
+    every sample the same bits as a batch of its own -- the reference has no batch limit."""
+    import torch
+    from gps_gaussian_amd.unproject import unproject
+    g = np.load(os.path.join(GOLDEN, "unproject_golden.npz"))
+    dev = torch.device("cuda:0")
+    B0 = g["flow"].shape[0]
+    idx = np.arange(37) % B0
+    args = lambda ii: (torch.from_numpy(g["mask"][ii]).to(dev), torch.from_numpy(g["ref_intr"][ii]), torch.from_numpy(g["intr"][ii]),
+                       torch.from_numpy(g["extr"][ii]), torch.from_numpy(g["Tf_x"][ii]))
+    flow = torch.from_numpy(g["flow"][idx]).to(dev).requires_grad_(True)
+    depth, xyz, valid = unproject(flow, *args(idx))
+    gx = torch.from_numpy(g["g_xyz"][idx]).to(dev)
+    (xyz * gx).sum().backward()
+    flow1 = torch.from_numpy(g["flow"]).to(dev).requires_grad_(True)
+    d1, x1, v1 = unproject(flow1, *args(np.arange(B0)))
+    (x1 * torch.from_numpy(g["g_xyz"]).to(dev)).sum().backward()
+    for b, src in enumerate(idx):
+        assert torch.equal(depth[b], d1[src]) and torch.equal(xyz[b], x1[src]) and torch.equal(valid[b], v1[src])
+        assert torch.equal(flow.grad[b], flow1.grad[src])
