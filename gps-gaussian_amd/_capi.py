@@ -18,7 +18,7 @@ _ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch faile
 GSR_FLAG_DEBUG = 1
 GSR_FLAG_NO_LARGE_SORT = 4
 GSR_FLAG_TIMING = 2
-GSR_FLAG_COMPOSITE_VALU = 8
+GSR_FLAG_COMPOSITE_TILES = 8
 STAGES = ("preprocess", "scan", "scatter", "sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 
 

@@ -159,10 +159,10 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
-        if (flags & GSR_FLAG_COMPOSITE_VALU)
-            gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+        if (flags & GSR_FLAG_COMPOSITE_TILES)
+            gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
         else
-            gsr_launch_composite_fwd_mfma(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+            gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
     }
     return check(s, flags);
 }
@@ -208,10 +208,10 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
         StageTimer t(flags, GSR_STAGE_COMPOSITE_BWD, s);
         // must be the same family as the forward that filled the workspace: the two designs round the exponent differently, and the
         // backward has to repeat the forward's per-pixel decisions
-        if (flags & GSR_FLAG_COMPOSITE_VALU)
-            gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_pos, inst_grad, hdr, s);
+        if (flags & GSR_FLAG_COMPOSITE_TILES)
+            gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_pos, inst_grad, hdr, s);
         else
-            gsr_launch_composite_bwd_mfma(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_pos, inst_grad, hdr, s);
+            gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_pos, inst_grad, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     GsrBwdParams b;

@@ -325,13 +325,13 @@ static inline unsigned gsr_debug_lds_pad() {
     if (v < 0) { const char *e = getenv("GPSGS_DEBUG_LDS_PAD"); v = e ? atoi(e) : 0; if (v < 0) v = 0; }
     return (unsigned)v;
 }
-// matrix-core variants (gsr_composite_mfma.hip): same arguments, same results within rounding
-void gsr_launch_composite_fwd_mfma(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
-                                   const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
-void gsr_launch_composite_bwd_mfma(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
-                                   const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
-                                   const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, GsrGradAcc *inst_grad, const GsrHeader *hdr,
-                                   hipStream_t s);
+// exponents from bf16 matrix-core tiles (gsr_composite_tiles.hip): same arguments, same results within rounding
+void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                                    const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
+void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                                    const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
+                                    const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, GsrGradAcc *inst_grad, const GsrHeader *hdr,
+                                    hipStream_t s);
 void gsr_launch_selftest(float *out4, hipStream_t s);
 struct GsrBwdParams {
     int P, W, H;

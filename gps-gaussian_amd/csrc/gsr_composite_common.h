@@ -75,4 +75,56 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 
+// ---- nine simultaneous wave64 sums as a butterfly REDUCE-SCATTER ------------------------------------------------------
+// Summing 9 values over 64 lanes one by one costs 9 x 6 = 54 DPP adds.  A reduce-scatter halves the number of live
+// registers at every level instead:  xor-32 level: v_permlane32_swap + add folds TWO values into one register (lower
+// half-wave = value a, upper = value b);  xor-16 level: v_permlane16_swap + add folds two of those (even rows / odd rows);
+// xor-8 level: one select pair + row_ror:8 add;  then 3 DPP adds inside each 8-lane group.  8 values: 8+4+3+3 = 18
+// instructions; the 9th is only row-reduced (4 DPP adds) and its 4 row sums are added at flush time.
+// Result: value k of v[0..7] sits (fully summed) in every lane of one 8-lane group, see acc_slot(); v[8]'s row sums
+// sit in lanes 15, 31, 47, 63.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_row(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float swap_add32(float a, float b) {  // lanes 0-31: a[l]+a[l+32], lanes 32-63: b[l-32]+b[l]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {  // even rows: a folded over row pairs, odd rows: b
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// which accumulator slot (0..11) this lane writes, or -1: lanes 0,8,..,56 hold v[0..7]; lanes 15,31,47,63 the 4 row sums of v[8]
+__device__ __forceinline__ int acc_slot(int lane) {
+    if ((lane & 7) == 0) {
+        const int grp = lane >> 3;  // (row, half): row0 -> v0|v4, row1 -> v2|v6, row2 -> v1|v5, row3 -> v3|v7
+        const int row = grp >> 1, half = grp & 1;
+        const int base = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;
+        return base + 4 * half;
+    }
+    if ((lane & 15) == 15) return 8 + (lane >> 4);
+    return -1;
+}
+__device__ __forceinline__ float wave_reduce_scatter9(const float (&v)[9], bool upper8) {
+    const float u0 = swap_add32(v[0], v[1]), u1 = swap_add32(v[2], v[3]);
+    const float u2 = swap_add32(v[4], v[5]), u3 = swap_add32(v[6], v[7]);
+    const float t0 = swap_add16(u0, u1);  // rows: v0, v2, v1, v3
+    const float t1 = swap_add16(u2, u3);  // rows: v4, v6, v5, v7
+    const float keep = upper8 ? t1 : t0, send = upper8 ? t0 : t1;
+    const int sw = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xF, 0xF, true);  // row_ror:8
+    float r = keep + __int_as_float(sw);
+    r = dpp_add_row<0x141>(r);  // row_half_mirror
+    r = dpp_add_row<0x1B>(r);   // quad_perm [3,2,1,0]
+    r = dpp_add_row<0xB1>(r);   // quad_perm [1,0,3,2]  -> every lane of an 8-lane group holds its value's wave sum
+    float w = v[8];
+    w = dpp_add_row<0xB1>(w);
+    w = dpp_add_row<0x4E>(w);   // quad_perm [2,3,0,1]
+    w = dpp_add_row<0x114>(w);  // row_shr:4
+    w = dpp_add_row<0x118>(w);  // row_shr:8 -> lane 15 of each row holds the row sum
+    return ((__lane_id() & 15) == 15) ? w : r;
+}
+
+
 }  // namespace

@@ -1,0 +1,350 @@
+// gsr_composite_tiles.hip -- forward and backward alpha compositing with the exponents taken from bf16 matrix-core tiles
+// (gsr_pow_tiles.h): ONE wave64 per 8x8-pixel bin, lane = pixel, everything else as in gsr_composite.hip.
+//
+// Semantics: SURVEY.md section 9.2 / 9.3 (upstream renderCUDA forward / backward, reached through
+// /root/reference/gaussian_renderer/__init__.py:54-62 and its autograd backward).
+//
+// Per round of 64 staged splats every lane turns ITS staged splat into 32 bf16 terms (fp64 coefficients about the bin centre, exact
+// hi / lo split), four v_permlane32_swap pairs arrange them as MFMA operands, and per half round (32 splats) four
+// v_mfma_f32_32x32x16_bf16 produce the exponents of 32 splats x 64 pixels into 32 registers.  The blend loop then starts at
+// v_exp_f32: the 8 VALU instructions per (pixel, splat) pair that computed dx, dy and the quadratic form are gone (forward 23 -> 15
+// per pair), for ~1.7 instructions per (bin, splat) of operand preparation and 4 cycles per (bin, splat) on the matrix pipe.
+// The backward still needs dx, dy for its moments, so it saves the 6-instruction quadratic form only.
+#include "gsr_pow_tiles.h"
+
+namespace {
+
+typedef unsigned long long lanemask_t;
+
+struct TileFwdState {
+    float T, C0, C1, C2;
+    uint32_t last_rnd;
+    lanemask_t active;
+};
+
+template <int S>
+__device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wCol, int cnt) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j0 = 32 * S + 8 * q;
+        // groups of 8; between groups one scalar test stops the round as soon as all 64 pixels are saturated
+        if (j0 < cnt && st.active != 0ull) {
+            float p[8];
+            pow_group8(d0, d1, q, p);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int j = j0 + e;
+                const float4 c = wCol[j];  // {opacity, r, g, b}: wave-uniform address (LDS broadcast)
+                // upstream skips power > 0, which its own (PSD) quadratic form never produces; the exact evaluation here can land one
+                // rounding above zero where the true exponent is 0 (splat centre on a pixel centre): clamp instead of skipping
+                const float alpha = fminf(0.99f, c.x * __builtin_amdgcn_exp2f(fminf(p[e], 0.f)));
+                const lanemask_t valid = st.active & ~__ballot(alpha < 1.f / 255.f);
+                const float test_T = __builtin_fmaf(-alpha, st.T, st.T);  // T (1 - alpha), one rounding
+                const lanemask_t sat = __ballot(test_T < 0.0001f);
+                st.active &= ~(valid & sat);
+                const bool use = __builtin_amdgcn_inverse_ballot_w64(valid & ~sat);
+                const float w = use ? alpha * st.T : 0.f;
+                st.C0 += c.y * w;
+                st.C1 += c.z * w;
+                st.C2 += c.w * w;
+                st.T = use ? test_T : st.T;
+                st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+                                                            const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                            const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
+                                                            float *__restrict__ out_color, float *__restrict__ final_T,
+                                                            uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr) {
+    __shared__ float4 sCol[WAVE];  // {opacity, r, g, b} of the 64 staged splats
+    const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
+    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    if (hdr->overflow) {  // nothing can be rendered from truncated lists: a deterministic zero image instead of uninitialised memory
+        fwd_write_blank(g, W, H, out_color, final_T, n_contrib);
+        return;
+    }
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);
+    const int lane = g.lane;
+    const float cx = (float)(g.px - (lane & 7)) + 3.5f, cy = (float)(g.py - (lane >> 3)) + 3.5f;  // bin centre
+    const PowOperandsB opB = pow_operands_b(lane);
+
+    TileFwdState st;
+    st.T = 1.f; st.C0 = 0.f; st.C1 = 0.f; st.C2 = 0.f;
+    st.last_rnd = 0;
+    st.active = __ballot(g.inside);
+    uint32_t last = 0;  // 1-based list position of the last splat that contributed (n_contrib)
+
+    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
+    float nC = 0.f;
+    if (r0 + lane < r1) {  // prefetch round 0
+        const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[r0 + lane]);
+        nA = s[0]; nB = s[1]; nC = s[2].x;
+    }
+    for (uint32_t base = r0; base < r1; base += WAVE) {
+        if (st.active == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
+        const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy));
+        wave_sync_lds();  // previous round fully consumed
+        sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
+        wave_sync_lds();
+        const uint32_t nk = base + WAVE + lane;
+        nB.y = 0.f;  // a slot without a splat blends nothing (opacity 0 -> alpha 0 < 1/255; stale x, y, conic stay finite)
+        if (nk < r1) {  // prefetch the next round while this one is blended
+            const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[nk]);
+            nA = s[0]; nB = s[1]; nC = s[2].x;
+        }
+        const int cnt = (int)min((uint32_t)WAVE, r1 - base);
+        {
+            const f32x16 d0 = pow_tile_bf16(opA.a[0], opB.b[0]), d1 = pow_tile_bf16(opA.a[0], opB.b[1]);
+            tiles_fwd_half<0>(st, d0, d1, sCol, cnt);
+        }
+        if (cnt > 32 && st.active != 0ull) {
+            const f32x16 d0 = pow_tile_bf16(opA.a[1], opB.b[0]), d1 = pow_tile_bf16(opA.a[1], opB.b[1]);
+            tiles_fwd_half<1>(st, d0, d1, sCol, cnt);
+        }
+        last = st.last_rnd ? (base - r0) + st.last_rnd : last;
+        st.last_rnd = 0;
+    }
+    if (g.inside) {
+        const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
+        final_T[q] = st.T;
+        n_contrib[q] = last;
+        out_color[q] = st.C0 + st.T * bg[0];
+        out_color[npix + q] = st.C1 + st.T * bg[1];
+        out_color[2 * npix + q] = st.C2 + st.T * bg[2];
+    }
+}
+
+// ---- backward: gsr_composite.hip's kernel (butterfly reduce-scatter of nine sums per (bin, splat), scalar colour-behind recurrence,
+// atomic-free per-instance records) with the exponent read from the tiles ---------------------------------------------------------
+struct TileBwdState {
+    float T, A;
+    lanemask_t touched;
+};
+
+template <int GQ>
+__device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wXY,
+                                                const float4 *__restrict__ wCol, float *__restrict__ wAccF, int lane, int slot, float pxf, float pyf,
+                                                uint32_t topu, uint32_t last, float dr, float dg, float db, float nTb) {
+    float p[8];
+    pow_group8(d0, d1, GQ & 3, p);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int j = 8 * GQ + e;
+        const float4 c = wCol[j];  // {opacity, r, g, b}
+        const float G = __builtin_amdgcn_exp2f(fminf(p[e], 0.f));  // clamp as in the forward
+        const float alpha = fminf(0.99f, c.x * G);
+        // staged slot j sits at list position top - j (slots beyond the front of the list: topu - j wraps to a huge position, and they carry opacity 0)
+        const lanemask_t valid_m = __ballot(last > topu - (uint32_t)j) & ~__ballot(alpha < 1.f / 255.f);
+        if (valid_m != 0ull) {  // wave-uniform
+            st.touched |= 1ull << j;
+            const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+            const float2 xy = *reinterpret_cast<const float2 *>(&wXY[j]);
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float Ge = valid ? G : 0.f;
+            const float ae = valid ? alpha : 0.f;
+            const float om = 1.f - ae;
+            const float rcp = __builtin_amdgcn_rcpf(om);
+            st.T = st.T * rcp;
+            const float cd = c.y * dr + c.z * dg + c.w * db;
+            const float w = ae * st.T;  // dchannel/dcolour
+            const float dL_dalpha = (cd - st.A) * st.T + nTb * rcp;
+            st.A = ae * cd + om * st.A;
+            const float m_0 = (c.x * dL_dalpha) * Ge;  // s = dL/dG * G, with dL/dG = opacity * dL/dalpha straight through the 0.99 clamp
+            const float m_x = m_0 * dx;
+            const float m_y = m_0 * dy;
+            const float red[9] = {w * dr, w * dg, w * db, m_x, m_y, m_x * dx, m_x * dy, m_y * dy, m_0};
+            const float out = wave_reduce_scatter9(red, (lane & 8) != 0);
+            if (slot >= 0) wAccF[12 * j + slot] = out;  // 12 lanes, 12 distinct words of this splat's record
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, 4) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+                                                            const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                            const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
+                                                            const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
+                                                            const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
+                                                            const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos,
+                                                            GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
+    __shared__ float4 sXY[WAVE];       // {x, y, A, B} of the staged splats (x, y for the moments; A, B for the flush)
+    __shared__ float4 sCol[WAVE];      // {opacity, r, g, b}
+    __shared__ float4 sAcc[WAVE * 3];  // per staged splat: {dr,dg,db,Sx | Sy,Sxx,Sxy,Syy | 4 row sums of S0}
+    if (hdr->overflow) return;
+    const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
+    if (list_pos >= hdr->num_busy_wgs) return;  // idle workgroups sit at the end of wg_order
+    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);
+    if (r1 <= r0) return;
+    const int lane = g.lane;
+    const float pxf = (float)g.px, pyf = (float)g.py;
+    const float cx = pxf - (float)(lane & 7) + 3.5f, cy = pyf - (float)(lane >> 3) + 3.5f;  // bin centre
+    const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
+    float *wAccF = reinterpret_cast<float *>(sAcc);
+    const int slot = acc_slot(lane);
+
+    const float T_final = g.inside ? final_T[q] : 0.f;
+    const uint32_t last = g.inside ? n_contrib[q] : 0u;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (g.inside) {
+        d0 = dL_dpix[q];
+        d1 = dL_dpix[npix + q];
+        d2 = dL_dpix[2 * npix + q];
+    }
+    const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+    // deepest contributor over the bin: nothing behind it receives gradient
+    uint32_t m = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    const int64_t max_last = (int64_t)__builtin_amdgcn_readfirstlane((int)m);
+    if (max_last == 0) return;
+    const PowOperandsB opB = pow_operands_b(lane);
+
+    TileBwdState st;
+    st.T = T_final; st.A = 0.f; st.touched = 0ull;
+    const float nTb = -T_final * bg_dot;
+
+    // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64
+    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
+    float nC = 0.f;
+    uint32_t nSlot = 0;  // where this lane's staged instance lives in its Gaussian's inst_pos slots
+    const int bin_x = g.bin % bx, bin_y = g.bin / bx;
+    auto stage = [&](int64_t pos) {
+        nB.y = 0.f;  // a slot without a splat blends nothing (opacity 0)
+        if (pos >= 0) {
+            const uint32_t id = point_list[r0 + (uint32_t)pos];
+            const float4 *s = reinterpret_cast<const float4 *>(splats + id);
+            nA = s[0]; nB = s[1];
+            const float4 c = s[2];
+            nC = c.x;
+            const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
+            const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
+            nSlot = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
+        }
+    };
+    stage(max_last - 1 - lane);
+    for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
+        const int cnt = (int)min((int64_t)WAVE, top + 1);
+        const uint32_t topu = (uint32_t)top;
+        const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy));
+        wave_sync_lds();  // previous round fully consumed
+        sXY[lane] = nA;
+        sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
+        const float sC_ = nB.x, sop = nB.y;  // this lane's own staged splat, for the flush
+        const uint32_t curSlot = nSlot;
+        wave_sync_lds();
+        stage(top - WAVE - lane);  // prefetch the next round
+        st.touched = 0ull;
+        {
+            const f32x16 t0 = pow_tile_bf16(opA.a[0], opB.b[0]), t1 = pow_tile_bf16(opA.a[0], opB.b[1]);
+            if (0 < cnt) tiles_bwd_group<0>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            if (8 < cnt) tiles_bwd_group<1>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            if (16 < cnt) tiles_bwd_group<2>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            if (24 < cnt) tiles_bwd_group<3>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+        }
+        if (32 < cnt) {
+            const f32x16 t0 = pow_tile_bf16(opA.a[1], opB.b[0]), t1 = pow_tile_bf16(opA.a[1], opB.b[1]);
+            tiles_bwd_group<4>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            if (40 < cnt) tiles_bwd_group<5>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            if (48 < cnt) tiles_bwd_group<6>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            if (56 < cnt) tiles_bwd_group<7>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+        }
+        wave_sync_lds();
+        if ((st.touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 48-byte instance record (no atomics)
+            const float4 v0 = sAcc[3 * lane], v1 = sAcc[3 * lane + 1], rs = sAcc[3 * lane + 2];
+            const float4 sa = sXY[lane];  // this lane staged splat `lane` itself: conic A = sa.z, B = sa.w, C = sC_
+            const float Sx = v0.w, Sy = v1.x, Sxx = v1.y, Sxy = v1.z, Syy = v1.w;
+            const float S0 = (rs.x + rs.y) + (rs.z + rs.w);  // arrives as 4 row sums
+            // dG/d(delta) = -G (A dx + B dy), -G (C dy + B dx);  dL/dconic = -0.5 s {dx^2, dx dy, dy^2};  dL/dop = G dL/dalpha = s / op
+            const float g_mx = ddelx_dx * (-sa.z * Sx - sa.w * Sy);
+            const float g_my = ddely_dy * (-sC_ * Sy - sa.w * Sx);
+            const uint32_t pp = r0 + (uint32_t)(top - lane);  // consecutive lanes -> consecutive records: coalesced
+            float4 *dst = reinterpret_cast<float4 *>(inst_grad + pp);
+            dst[0] = make_float4(v0.x, v0.y, v0.z, g_mx);
+            dst[1] = make_float4(g_my, -0.5f * Sxx, -0.5f * Sxy, -0.5f * Syy);
+            dst[2] = make_float4(S0 * __builtin_amdgcn_rcpf(sop), 0.f, 0.f, 0.f);
+            inst_pos[curSlot] = pp;
+        }
+    }
+}
+
+// ---- device self-test of the tile plumbing (gsr_selftest): the SAME device functions the kernels use, on pseudo-random splats
+// around a bin, against the quadratic form evaluated per lane in fp64.  out[0] = max |tile - fp64| / (1 + |value|) over 64 splats x 64
+// pixels, out[1] = the same restricted to pairs with exponent > -12 natural units (the ones that can pass the alpha test),
+// out[2] = 1 if v_permlane32_swap behaves as documented, out[3] = largest |c0| met (log2 units).
+__global__ __launch_bounds__(64) void k_selftest_tiles(float *__restrict__ out) {
+    __shared__ float sP[WAVE][WAVE + 1];  // [splat][pixel] exponents
+    __shared__ float sRec[WAVE][5];
+    const int lane = threadIdx.x;
+    auto rnd = [](uint32_t a) {
+        a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+        return (float)(a & 0xffffff) * (1.f / 16777216.f);
+    };
+    uint32_t lo, hi;
+    gsr_swap32((uint32_t)lane, (uint32_t)(lane + 100), lo, hi);
+    const bool swap_ok = (lane < 32 ? (lo == (uint32_t)lane && hi == (uint32_t)(lane + 32)) : (lo == (uint32_t)(lane + 100 - 32) && hi == (uint32_t)(lane + 100)));
+    const float cx = 515.5f, cy = 259.5f;
+    // centres up to ~15 px from the bin centre, conic eigenvalues up to 1/0.3 (the dilation bound), arbitrary orientation
+    const float x = cx + (rnd(lane * 7 + 1) - 0.5f) * 30.f, y = cy + (rnd(lane * 7 + 2) - 0.5f) * 30.f;
+    const float a = 0.02f + 3.3f * rnd(lane * 7 + 3), c = 0.02f + 3.3f * rnd(lane * 7 + 4), b = (rnd(lane * 7 + 5) - 0.5f) * 1.9f * sqrtf(a * c);
+    sRec[lane][0] = x; sRec[lane][1] = y; sRec[lane][2] = a; sRec[lane][3] = b; sRec[lane][4] = c;
+    const PowOperandsA opA = pow_operands_a(pow_terms(x, y, a, b, c, cx, cy));
+    const PowOperandsB opB = pow_operands_b(lane);
+#pragma unroll
+    for (int S = 0; S < 2; S++) {
+        const f32x16 d0 = pow_tile_bf16(opA.a[S], opB.b[0]), d1 = pow_tile_bf16(opA.a[S], opB.b[1]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float p[8];
+            pow_group8(d0, d1, q, p);
+#pragma unroll
+            for (int e = 0; e < 8; e++) sP[32 * S + 8 * q + e][lane] = p[e];
+        }
+    }
+    __syncthreads();
+    float e0 = 0.f, e1 = 0.f, c0max = 0.f;
+    const double px = (double)cx - 3.5 + (lane & 7), py = (double)cy - 3.5 + (lane >> 3);
+    for (int j = 0; j < WAVE; j++) {
+        const double dx = (double)sRec[j][0] - px, dy = (double)sRec[j][1] - py;
+        const double nat = -0.5 * ((double)sRec[j][2] * dx * dx + (double)sRec[j][4] * dy * dy) - (double)sRec[j][3] * dx * dy;
+        const double ref = nat * GSR_LOG2E_D;
+        const float err = (float)(fabs((double)sP[j][lane] - ref) / (1.0 + fabs(ref)));
+        e0 = fmaxf(e0, err);
+        if (nat > -12.0) e1 = fmaxf(e1, err);
+        const double X = (double)sRec[j][0] - cx, Y = (double)sRec[j][1] - cy;
+        c0max = fmaxf(c0max, (float)fabs(0.5 * GSR_LOG2E_D * ((double)sRec[j][2] * X * X + 2.0 * sRec[j][3] * X * Y + (double)sRec[j][4] * Y * Y)));
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        e0 = fmaxf(e0, __shfl_xor(e0, dd, 64)); e1 = fmaxf(e1, __shfl_xor(e1, dd, 64)); c0max = fmaxf(c0max, __shfl_xor(c0max, dd, 64));
+    }
+    const unsigned long long okm = __ballot(swap_ok);
+    if (lane == 0) { out[0] = e0; out[1] = e1; out[2] = (okm == ~0ull) ? 1.f : 0.f; out[3] = c0max; }
+}
+
+}  // namespace
+
+void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                                    const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
+                                    const GsrHeader *hdr, hipStream_t s) {
+    const int wgs = bx * by;
+    if (wgs <= 0) return;
+    hipLaunchKernelGGL(k_composite_fwd_tiles, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
+                       out_color, final_T, n_contrib, hdr);
+}
+
+void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+                                    const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
+                                    const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos,
+                                    GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
+    const int wgs = bx * by;
+    if (wgs <= 0) return;
+    hipLaunchKernelGGL(k_composite_bwd_tiles, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
+                       dL_dpix, final_T, n_contrib, goff, gpart, inst_pos, inst_grad, hdr);
+}
+
+void gsr_launch_selftest(float *out, hipStream_t s) { hipLaunchKernelGGL(k_selftest_tiles, dim3(1), dim3(64), 0, s, out); }

@@ -81,14 +81,16 @@ def _capacity_for(st, P):
 
 
 def _composite_flag():
-    """GPSGS_COMPOSITE=valu (default): the vector-ALU compositing kernels (gsr_composite.hip).  GPSGS_COMPOSITE=mfma: the experimental
-    family that evaluates the exponents and the backward's wave reductions with fp32 MFMA instructions (gsr_composite_mfma.hip);
-    measured slower on MI355X (fp32 MFMA does not overlap with VALU work there) and its dL/dconic is ~10x less
-    precise (moments about the bin centre), kept as a documented experiment."""
-    m = os.environ.get("GPSGS_COMPOSITE", "valu")
-    if m not in ("mfma", "valu"):
-        raise ValueError("GPSGS_COMPOSITE must be 'mfma' or 'valu'")
-    return _capi.GSR_FLAG_COMPOSITE_VALU if m == "valu" else 0
+    """GPSGS_COMPOSITE=valu: the compositing kernels that evaluate every (pixel, splat) exponent on the vector ALUs (gsr_composite.hip).
+    GPSGS_COMPOSITE=tiles: the kernels that take the exponents from bf16 matrix-core tiles (gsr_composite_tiles.hip; exact split
+    evaluation, same results within rounding)."""
+    m = os.environ.get("GPSGS_COMPOSITE", _DEFAULT_FAMILY)
+    if m not in ("valu", "tiles"):
+        raise ValueError("GPSGS_COMPOSITE must be 'valu' or 'tiles'")
+    return _capi.GSR_FLAG_COMPOSITE_TILES if m == "tiles" else 0
+
+
+_DEFAULT_FAMILY = "tiles"
 
 
 def _check_mode():

@@ -54,9 +54,9 @@ enum {
 #define GSR_FLAG_NO_LARGE_SORT 4u /* the caller expects no bin list longer than 1024 entries: the (normally idle) 1024-thread sort
                                     launch is skipped.  If a longer list does turn up, the scan reports it as an OVERFLOW (nothing is
                                     rendered; max_tile_count > 1024 in the header tells the two cases apart): call again without it */
-#define GSR_FLAG_COMPOSITE_VALU 8u /* compositing on the vector ALUs only (gsr_composite.hip) instead of the default kernels that
-                                     evaluate the exponents and the backward's wave reductions on the matrix cores
-                                     (gsr_composite_mfma.hip).  Forward and backward of one view must agree on it. */
+#define GSR_FLAG_COMPOSITE_TILES 8u /* compositing kernels that take the exponents of all (pixel, splat) pairs from bf16 matrix-core
+                                      tiles (gsr_composite_tiles.hip, exact split evaluation) instead of computing them per pair on the
+                                      vector ALUs (gsr_composite.hip).  Forward and backward of one view must agree on it. */
 #define GSR_FLAG_TIMING_STAGE(k) (GSR_FLAG_TIMING | (((unsigned)(k) + 1u) << 4)) /* ... or only stage k (GSR_STAGE_*) */
 
 /* stage ids reported by gsr_timing_read() */
@@ -128,9 +128,10 @@ int gsr_copy_header_async(const void *workspace, void *host_pinned_out, void *st
 /* Blocking helper for non-torch hosts: copies the header to host memory and synchronises `stream`. */
 int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream);
 
-/* Diagnostic: runs the matrix-core building blocks of the compositing kernels (exponent tiles, transposed reductions) on
- * pseudo-random operands against plain per-lane evaluation.  out4 (device): {max exponent error / (1 + |value|), max relative
- * error of the reduction sums, 1 if v_permlane32_swap behaves as documented else 0, 0}. */
+/* Diagnostic: runs the matrix-core building blocks of the tile compositing kernels (coefficient split, operand arrangement, bf16
+ * MFMA tiles, lane exchange) on pseudo-random splats against the quadratic form evaluated per lane in fp64.  out4 (device): {max
+ * |error| / (1 + |value|) over 64 splats x 64 pixels, the same over pairs that can pass the alpha test, 1 if v_permlane32_swap behaves
+ * as documented else 0, the largest |c0| met}. */
 int gsr_selftest(float *out4_device, void *stream);
 
 /* Profiling helper (not thread safe, not for use under graph capture): synchronises, then adds up the hipEvent

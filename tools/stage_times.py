@@ -8,7 +8,7 @@ import gps_gaussian_amd  # noqa
 from gps_gaussian_amd import _capi, synthetic as S, rasterizer as RZ
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--families", default="mfma,valu")
+ap.add_argument("--families", default="tiles,valu")
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--render-res", type=int, default=None)
 ap.add_argument("--gaussians", type=int, default=600000)
