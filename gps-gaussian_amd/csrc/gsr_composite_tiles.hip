@@ -35,9 +35,10 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
             for (int e = 0; e < 8; e++) {
                 const int j = j0 + e;
                 const float4 c = wCol[j];  // {opacity, r, g, b}: wave-uniform address (LDS broadcast)
-                // upstream skips power > 0, which its own (PSD) quadratic form never produces; the exact evaluation here can land one
-                // rounding above zero where the true exponent is 0 (splat centre on a pixel centre): clamp instead of skipping
-                const float alpha = fminf(0.99f, c.x * __builtin_amdgcn_exp2f(fminf(p[e], 0.f)));
+                // upstream skips power > 0, which its own (PSD) quadratic form never produces.  The exact evaluation here can land one
+                // rounding above zero where the true exponent is 0 (splat centre on a pixel centre): such a pair is blended (exp2 of
+                // +1e-7 is 1 to fp32 precision), never skipped
+                const float alpha = fminf(0.99f, c.x * __builtin_amdgcn_exp2f(p[e]));
                 const lanemask_t valid = st.active & ~__ballot(alpha < 1.f / 255.f);
                 const float test_T = __builtin_fmaf(-alpha, st.T, st.T);  // T (1 - alpha), one rounding
                 const lanemask_t sat = __ballot(test_T < 0.0001f);
@@ -130,25 +131,33 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
                                                 uint32_t topu, uint32_t last, float dr, float dg, float db, float nTb) {
     float p[8];
     pow_group8(d0, d1, GQ & 3, p);
+    // the {opacity, r, g, b} and {x, y} of staged splat j + 1 are fetched from LDS while splat j is processed (the loads sit ahead of
+    // the wave-uniform skip branch and are consumed after it: their latency hides under the ~55 instructions of the body)
+    float4 cn = wCol[8 * GQ];
+    float2 xyn = *reinterpret_cast<const float2 *>(&wXY[8 * GQ]);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int j = 8 * GQ + e;
-        const float4 c = wCol[j];  // {opacity, r, g, b}
-        const float G = __builtin_amdgcn_exp2f(fminf(p[e], 0.f));  // clamp as in the forward
+        const float4 c = cn;  // {opacity, r, g, b}
+        const float2 xy = xyn;
+        if (e < 7) {
+            cn = wCol[j + 1];
+            xyn = *reinterpret_cast<const float2 *>(&wXY[j + 1]);
+        }
+        const float dx = xy.x - pxf, dy = xy.y - pyf;
+        const float cd = c.y * dr + c.z * dg + c.w * db;
+        const float G = __builtin_amdgcn_exp2f(p[e]);  // as the forward: no power > 0 skip
         const float alpha = fminf(0.99f, c.x * G);
         // staged slot j sits at list position top - j (slots beyond the front of the list: topu - j wraps to a huge position, and they carry opacity 0)
         const lanemask_t valid_m = __ballot(last > topu - (uint32_t)j) & ~__ballot(alpha < 1.f / 255.f);
         if (valid_m != 0ull) {  // wave-uniform
             st.touched |= 1ull << j;
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
-            const float2 xy = *reinterpret_cast<const float2 *>(&wXY[j]);
-            const float dx = xy.x - pxf, dy = xy.y - pyf;
             const float Ge = valid ? G : 0.f;
             const float ae = valid ? alpha : 0.f;
             const float om = 1.f - ae;
             const float rcp = __builtin_amdgcn_rcpf(om);
             st.T = st.T * rcp;
-            const float cd = c.y * dr + c.z * dg + c.w * db;
             const float w = ae * st.T;  // dchannel/dcolour
             const float dL_dalpha = (cd - st.A) * st.T + nTb * rcp;
             st.A = ae * cd + om * st.A;
