@@ -380,7 +380,7 @@ def main():
         if R_tile and dom in ("composite_fwd", "composite_bwd"):  # the same formula with SURVEY's 16x16-tile instance count (T = 16x16 tiles)
             T16 = ((W + 15) // 16) * ((H + 15) // 16)
             alg_tile = 40 * R_tile + 8 * T16 + 20 * npix + (44 * P if dom == "composite_bwd" else 0)
-        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_tiles" if (dom.startswith("composite") and RZ._composite_flag()) else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_src,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": dom_us,
                     "views_in_flight": F, "avg_launch_us_one_view_in_flight": round(serial_dom_us, 2),

@@ -7,6 +7,7 @@ do not need /root/reference on the path, and they read the camera scalars withou
 tensors already live on the host.
 """
 import math
+import os
 
 import torch
 
@@ -106,10 +107,13 @@ def pts2render(data, bg_color):
     dev = xyz.device
     cur = torch.cuda.current_stream(dev)
     # One view's kernels leave the chip under-occupied (~5 one-wave compositing work items per SIMD at 1024^2 / 600k Gaussians), and the
-    # samples of a batch are independent: each is enqueued on its own HIP stream so that they render concurrently (the reference loops
-    # over them on one stream, lib/GaussianRender.py:9).  Their capacity checks are collected and run after all of them are in flight;
-    # autograd runs every sample's backward on the stream of its forward, so the backward passes overlap the same way.
-    side = _streams(dev, bs) if (bs > 1 and not torch.cuda.is_current_stream_capturing()) else [cur] * bs
+    # samples of a batch are independent: with GPSGS_PTS2RENDER_STREAMS=1 each is enqueued on its own HIP stream so that they render
+    # concurrently (the reference loops over them on one stream, lib/GaussianRender.py:9); their capacity checks are collected and run
+    # after all of them are in flight, and autograd runs every sample's backward on the stream of its forward.  Off by default: through
+    # PyTorch's autograd the batch loop is host-bound (tools/stage2_ab.py: 2.73 ms vs 2.79 ms per iteration of 4 pairs), so the overlap
+    # that the C-ABI sessions get (bench.py --inflight: +27 %) does not materialise here.
+    concurrent = bs > 1 and not torch.cuda.is_current_stream_capturing() and os.environ.get("GPSGS_PTS2RENDER_STREAMS", "0") == "1"
+    side = _streams(dev, bs) if concurrent else [cur] * bs
     with _RZ.defer_capacity_checks():
         for i in range(bs):
             # arena order expected by the rasteriser: means3D, colours, opacities, scales, rotations

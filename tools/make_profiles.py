@@ -47,12 +47,12 @@ def main(d, tag):
         m = re.search(r"(\d+)x(\d+) render.*P=(\d+) Gaussians, R=(\d+)", bench["config"]["workload"])
         if m:
             out["workload"] = {"W": int(m.group(1)), "H": int(m.group(2)), "P": int(m.group(3)), "R": int(m.group(4))}
-    names = {"k_composite_bwd": "composite_bwd", "k_composite_fwd": "composite_fwd", "k_preprocess": "preprocess", "k_preprocess_bwd": "preprocess_bwd",
-             "k_scatter": "scatter", "k_sort_wave": "sort"}
+    names = {"k_composite_bwd": "composite_bwd", "k_composite_fwd": "composite_fwd", "k_composite_bwd_tiles": "composite_bwd", "k_composite_fwd_tiles": "composite_fwd",
+             "k_preprocess": "preprocess", "k_preprocess_bwd": "preprocess_bwd", "k_scatter": "scatter", "k_sort_wave": "sort"}
     for k, v in agg.items():
         if k in names and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             f, w = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
-            e = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1)}
+            e = {"kernel": k, "hbm_bytes_per_launch": int((2 * f + w) * 1024), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1)}
             if "SQ_INSTS_VALU" in v:
                 e["valu_wave_instructions_per_launch"] = sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"])
             out[names[k]] = e
