@@ -452,12 +452,15 @@ def main():
             graph_res = {"error": repr(e)[:200]}
 
     if rank == 0:
+        cfg_name = ("BASELINE config 2" if (args.res, args.gaussians, W) == (1024, 600000, 1024) else
+                    "BASELINE config 2 rendered at 2048^2 (use_hr_img)" if (args.res, args.gaussians, W) == (1024, 600000, 2048) else
+                    "BASELINE config 5" if (args.res, args.gaussians, W) == (2048, 2400000, 2048) else "non-BASELINE workload (parity / contract test size)")
         line = {
             "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward", "value": round(value, 2),
             "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d (Gaussian, 8x8-bin) instances, "
-                                   "HIP rasteriser forward+backward, one view per step per GPU" % (W, H, P, R),
+            "config": {"workload": "%s: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d (Gaussian, 8x8-bin) instances, "
+                                   "HIP rasteriser forward+backward, one view per step per GPU" % (cfg_name, W, H, P, R),
                        "host": "C-ABI (gsr_forward_notify + gsr_backward) driven by gps_gaussian_amd.session.RasterSession: preallocated buffers, no "
                                "autograd round trip; the same step through the drop-in autograd module is `autograd_api_views_per_s`",
                        "views_in_flight": "%d independent views per GPU rendered concurrently (one session + HIP stream each); one at a time: "

@@ -67,6 +67,55 @@ __global__ __launch_bounds__(256) void k_cs_bwd(const float *__restrict__ coords
     stf(grad_volume + e, g);
 }
 
+// Same result, four consecutive x1 per thread (W2 % 4 == 0: every pyramid level of the reference's shapes): one coords load, at most five
+// grad_out loads and ONE 16-byte (fp32) / 8-byte (fp16) store per thread instead of four of each -- the kernel is a pure store stream
+// (grad_volume is 3.6x the bytes of everything it reads).  Per element the same two products are added in the same order as in k_cs_bwd.
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+template <> struct Vec4<__half> { typedef uint2 type; };
+__device__ __forceinline__ float4 pack4(const float (&g)[4], float) { return make_float4(g[0], g[1], g[2], g[3]); }
+__device__ __forceinline__ uint2 pack4(const float (&g)[4], __half) {
+    const __half2 a = __halves2half2(__float2half(g[0]), __float2half(g[1])), b = __halves2half2(__float2half(g[2]), __float2half(g[3]));
+    return make_uint2(*reinterpret_cast<const uint32_t *>(&a), *reinterpret_cast<const uint32_t *>(&b));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_cs_bwd4(const float *__restrict__ coords, const T *__restrict__ grad_out,
+                                                 T *__restrict__ grad_volume, size_t total4, int H1, int W1, int W2, int r) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;  // quad index: (((n*H1 + y)*W1 + x)*W2 + x1) / 4
+    if (q >= total4) return;
+    const int wq = W2 >> 2;
+    const int x1 = (int)(q % wq) * 4;
+    const size_t idx = q / wq;
+    const int hw = H1 * W1;
+    const int n = (int)(idx / hw), yx = (int)(idx - (size_t)n * hw);
+    const float x0 = coords[idx];
+    const float fl = floorf(x0);
+    const float dx = x0 - fl;
+    const int rd = 2 * r + 1;
+    const int i0 = x1 - ((int)fl - r);  // tap index of the first element
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i0 + 3 >= 0 && i0 <= rd) {
+        const T *go = grad_out + (size_t)n * rd * hw + yx;
+        float t[5];  // grad_out taps i0-1 .. i0+3 (zero outside 0..rd-1: those terms are skipped below, as in k_cs_bwd)
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = i0 - 1 + k;
+            t[k] = (i >= 0 && i < rd) ? ldf(go + (size_t)i * hw) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k;
+            float v = 0.f;
+            if (i >= 0 && i <= rd) {
+                if (i > 0) v += t[k] * dx;
+                if (i < rd) v += t[k + 1] * (1.0f - dx);
+            }
+            g[k] = v;
+        }
+    }
+    *reinterpret_cast<typename Vec4<T>::type *>(grad_volume + q * 4) = pack4(g, T());
+}
+
 }  // namespace
 
 extern "C" int cs_forward(const void *volume, const float *coords, void *out, int N, int H1, int W1, int W2, int radius, int dtype,
@@ -91,6 +140,15 @@ extern "C" int cs_backward(const float *coords, const void *grad_out, void *grad
     if (total == 0) return GPSGS_OK;
     if (!coords || !grad_out || !grad_volume) return GPSGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    if ((W2 & 3) == 0 && ((uintptr_t)grad_volume & 15) == 0) {
+        const size_t total4 = total / 4;
+        const dim3 grid4((unsigned)((total4 + 255) / 256));
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_cs_bwd4<float>, grid4, dim3(256), 0, s, coords, (const float *)grad_out, (float *)grad_volume, total4, H1, W1, W2, radius);
+        else
+            hipLaunchKernelGGL(k_cs_bwd4<__half>, grid4, dim3(256), 0, s, coords, (const __half *)grad_out, (__half *)grad_volume, total4, H1, W1, W2, radius);
+        return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+    }
     const dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == 0)
         hipLaunchKernelGGL(k_cs_bwd<float>, grid, dim3(256), 0, s, coords, (const float *)grad_out, (float *)grad_volume, total, H1, W1, W2, radius);

@@ -31,7 +31,7 @@ def test_forward_backward_match_reference_golden_fp32():
         np.testing.assert_allclose(gv.cpu().numpy(), g["grad_volume%d" % lvl], rtol=0, atol=2e-5 * float(go.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(4, 128, 128, 128), (4, 128, 128, 16), (1, 3, 5, 7), (2, 9, 33, 64)])
+@pytest.mark.parametrize("shape", [(4, 128, 128, 128), (4, 128, 128, 16), (1, 3, 5, 7), (2, 9, 33, 64), (2, 5, 9, 12), (1, 2, 3, 4)])
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
 def test_bit_exact_against_oracle_at_model_sizes(shape, dtype):
     """Shapes the model uses at 1024^2 (features 128x128, pyramid widths 128..16).  fp32: bit-exact vs the CPU oracle
