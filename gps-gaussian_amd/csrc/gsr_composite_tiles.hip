@@ -9,7 +9,7 @@
 // v_mfma_f32_32x32x16_bf16 produce the exponents of 32 splats x 64 pixels into 32 registers.  The blend loop then starts at
 // v_exp_f32: the 8 VALU instructions per (pixel, splat) pair that computed dx, dy and the quadratic form are gone (forward 23 -> 15
 // per pair), for ~1.7 instructions per (bin, splat) of operand preparation and 4 cycles per (bin, splat) on the matrix pipe.
-// The backward still needs dx, dy for its moments, so it saves the 6-instruction quadratic form only.
+// The backward's pair body needs no dx, dy either: its sums over the pixels are formed in a second phase with lane = (splat, pixel row).
 #include "gsr_pow_tiles.h"
 
 namespace {
@@ -118,60 +118,101 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
     }
 }
 
-// ---- backward: gsr_composite.hip's kernel (butterfly reduce-scatter of nine sums per (bin, splat), scalar colour-behind recurrence,
-// atomic-free per-instance records) with the exponent read from the tiles ---------------------------------------------------------
+// ---- backward: scalar colour-behind recurrence and atomic-free per-instance records as in gsr_composite.hip, exponents from the tiles,
+// and the nine per-(bin, splat) sums over the 64 pixels taken in TWO PHASES instead of a 64-lane butterfly per splat:
+//   phase 1 (lane = pixel, 8 staged splats): the per-pixel recurrences; each (pixel, splat) pair leaves just two numbers in LDS:
+//       s = dL/dG * G   and   w = alpha * T (dchannel/dcolour);
+//   phase 2 (lane = (splat j = lane & 7, pixel row = lane >> 3)): the lane reads the 8 pixels of its row for its splat (two
+//       ds_read_b128 per array, XOR-swizzled: conflict-free on both sides), forms the colour sums and the moments of s about the
+//       splat centre with every lane busy, and a 3-level reduce-scatter over the 8 rows (permlane32 / permlane16 swaps, one DPP
+//       rotation) finishes 8 splats at once: ~11 VALU instructions per (bin, splat) instead of 9 products + 22 of butterfly,
+//       and the pair body no longer needs dx, dy at all.
 struct TileBwdState {
     float T, A;
     lanemask_t touched;
 };
+struct TileBwdConst {
+    float *wr[4];        // phase 1: this lane's word of a splat's 64-pixel row, for the four swizzles f(e) = 4 (e & 1) + 32 ((e >> 1) & 1)
+    const float4 *rdA;   // phase 2: pixels u = 0..3 of (splat j, row); rdB: u = 4..7
+    const float4 *rdB;
+    float *acc;          // phase 2: &wAccF[12 * j + slot(row group)]
+    float *acc0;         // phase 2: &wAccF[12 * j + 8 + (lane >> 4)]  (the four 16-lane partial sums of S0)
+    float pyrow;         // pixel-centre y of this lane's phase-2 row
+    float dr[8], dg[8], db[8];  // dL/dpixel of the 8 pixels of that row
+};
+constexpr int TILE_SW_WORDS = 8 * WAVE;  // one array (s or w): 8 splats x 64 pixels
+
+template <int GQ>
+__device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const float4 *__restrict__ wXY, const float (&pxu)[8], int lane) {
+    const float4 s0 = k.rdA[0], s1 = k.rdB[0];
+    const float4 w0 = k.rdA[TILE_SW_WORDS / 4], w1 = k.rdB[TILE_SW_WORDS / 4];
+    const float2 xy = *reinterpret_cast<const float2 *>(&wXY[8 * GQ + (lane & 7)]);
+    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float S0 = 0.f, Sx = 0.f, Sxx = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const float dx = xy.x - pxu[u];  // the same single rounding as x - (float)px
+        const float mx = sv[u] * dx;
+        S0 += sv[u];
+        Sx += mx;
+        Sxx = __builtin_fmaf(mx, dx, Sxx);
+        cr = __builtin_fmaf(wv[u], k.dr[u], cr);
+        cg = __builtin_fmaf(wv[u], k.dg[u], cg);
+        cb = __builtin_fmaf(wv[u], k.db[u], cb);
+    }
+    const float dy = xy.y - k.pyrow;  // constant along the row
+    const float Sy = dy * S0, Sxy = dy * Sx;
+    const float Syy = dy * Sy;
+    // reduce-scatter over the 8 rows (lane bits 5, 4, 3); lane bits 0..2 (the splat) are preserved by every step
+    const float u0 = swap_add32(cr, cg), u1 = swap_add32(cb, Sx), u2 = swap_add32(Sy, Sxx), u3 = swap_add32(Sxy, Syy);
+    const float t0 = swap_add16(u0, u1), t1 = swap_add16(u2, u3);
+    const bool upper8 = (lane & 8) != 0;
+    const float keep = upper8 ? t1 : t0, send = upper8 ? t0 : t1;
+    const float r = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xF, 0xF, true));  // row_ror:8
+    const float z = dpp_add_row<0x128>(S0);
+    k.acc[12 * 8 * GQ] = r;
+    if (!upper8) k.acc0[12 * 8 * GQ] = z;
+}
 
 template <int GQ>
 __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wXY,
-                                                const float4 *__restrict__ wCol, float *__restrict__ wAccF, int lane, int slot, float pxf, float pyf,
+                                                const float4 *__restrict__ wCol, const TileBwdConst &k, const float (&pxu)[8], int lane,
                                                 uint32_t topu, uint32_t last, float dr, float dg, float db, float nTb) {
     float p[8];
     pow_group8(d0, d1, GQ & 3, p);
-    // the {opacity, r, g, b} and {x, y} of staged splat j + 1 are fetched from LDS while splat j is processed (the loads sit ahead of
-    // the wave-uniform skip branch and are consumed after it: their latency hides under the ~55 instructions of the body)
+    // {opacity, r, g, b} of staged splat j + 1 is fetched from LDS while splat j is processed (the load sits ahead of the wave-uniform
+    // skip branch and is consumed after it)
     float4 cn = wCol[8 * GQ];
-    float2 xyn = *reinterpret_cast<const float2 *>(&wXY[8 * GQ]);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int j = 8 * GQ + e;
         const float4 c = cn;  // {opacity, r, g, b}
-        const float2 xy = xyn;
-        if (e < 7) {
-            cn = wCol[j + 1];
-            xyn = *reinterpret_cast<const float2 *>(&wXY[j + 1]);
-        }
-        const float dx = xy.x - pxf, dy = xy.y - pyf;
+        if (e < 7) cn = wCol[j + 1];
         const float cd = c.y * dr + c.z * dg + c.w * db;
-        const float G = __builtin_amdgcn_exp2f(p[e]);  // as the forward: no power > 0 skip
-        const float alpha = fminf(0.99f, c.x * G);
+        const float aG = c.x * __builtin_amdgcn_exp2f(p[e]);  // as the forward: no power > 0 skip
+        const float alpha = fminf(0.99f, aG);
         // staged slot j sits at list position top - j (slots beyond the front of the list: topu - j wraps to a huge position, and they carry opacity 0)
         const lanemask_t valid_m = __ballot(last > topu - (uint32_t)j) & ~__ballot(alpha < 1.f / 255.f);
         if (valid_m != 0ull) {  // wave-uniform
             st.touched |= 1ull << j;
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
-            const float Ge = valid ? G : 0.f;
             const float ae = valid ? alpha : 0.f;
+            const float aGe = valid ? aG : 0.f;  // dalpha/dG * G = opacity * G, straight through the 0.99 clamp
             const float om = 1.f - ae;
             const float rcp = __builtin_amdgcn_rcpf(om);
             st.T = st.T * rcp;
-            const float w = ae * st.T;  // dchannel/dcolour
             const float dL_dalpha = (cd - st.A) * st.T + nTb * rcp;
             st.A = ae * cd + om * st.A;
-            const float m_0 = (c.x * dL_dalpha) * Ge;  // s = dL/dG * G, with dL/dG = opacity * dL/dalpha straight through the 0.99 clamp
-            const float m_x = m_0 * dx;
-            const float m_y = m_0 * dy;
-            const float red[9] = {w * dr, w * dg, w * db, m_x, m_y, m_x * dx, m_x * dy, m_y * dy, m_0};
-            const float out = wave_reduce_scatter9(red, (lane & 8) != 0);
-            if (slot >= 0) wAccF[12 * j + slot] = out;  // 12 lanes, 12 distinct words of this splat's record
+            k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
+            k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
         }
     }
+    // splats of the group that no pixel touched leave stale numbers in their rows: their sums are never flushed (touched bit clear)
+    if ((st.touched >> (8 * GQ)) & 0xffull) tiles_bwd_phase2<GQ>(k, wXY, pxu, lane);
 }
 
-__global__ __launch_bounds__(64, 4) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+__global__ __launch_bounds__(64, 3) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
@@ -180,7 +221,8 @@ __global__ __launch_bounds__(64, 4) void k_composite_bwd_tiles(int W, int H, int
                                                             GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sXY[WAVE];       // {x, y, A, B} of the staged splats (x, y for the moments; A, B for the flush)
     __shared__ float4 sCol[WAVE];      // {opacity, r, g, b}
-    __shared__ float4 sAcc[WAVE * 3];  // per staged splat: {dr,dg,db,Sx | Sy,Sxx,Sxy,Syy | 4 row sums of S0}
+    __shared__ float4 sAcc[WAVE * 3];  // per staged splat: {dr,dg,db,Sx | Sy,Sxx,Sxy,Syy | 4 partial sums of S0}
+    __shared__ float4 sSW[2 * TILE_SW_WORDS / 4];  // phase 1 -> phase 2: s[8 splats][64 pixels], w[8][64], rows XOR-swizzled
     if (hdr->overflow) return;
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     if (list_pos >= hdr->num_busy_wgs) return;  // idle workgroups sit at the end of wg_order
@@ -192,7 +234,6 @@ __global__ __launch_bounds__(64, 4) void k_composite_bwd_tiles(int W, int H, int
     const float cx = pxf - (float)(lane & 7) + 3.5f, cy = pyf - (float)(lane >> 3) + 3.5f;  // bin centre
     const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
     float *wAccF = reinterpret_cast<float *>(sAcc);
-    const int slot = acc_slot(lane);
 
     const float T_final = g.inside ? final_T[q] : 0.f;
     const uint32_t last = g.inside ? n_contrib[q] : 0u;
@@ -212,6 +253,31 @@ __global__ __launch_bounds__(64, 4) void k_composite_bwd_tiles(int W, int H, int
     const int64_t max_last = (int64_t)__builtin_amdgcn_readfirstlane((int)m);
     if (max_last == 0) return;
     const PowOperandsB opB = pow_operands_b(lane);
+
+    // phase-2 constants of this lane = (splat j = lane & 7 of a group of 8, pixel row = lane >> 3)
+    TileBwdConst k;
+    float pxu[8];  // pixel-centre x of the bin's 8 columns: wave-uniform (scalar registers)
+    {
+        float *sw = reinterpret_cast<float *>(sSW);
+        const int j = lane & 7, row = lane >> 3;
+#pragma unroll
+        for (int f = 0; f < 4; f++) k.wr[f] = sw + (lane ^ (4 * (f & 1) + 32 * (f >> 1)));
+        const int fj = 4 * (j & 1) + 32 * ((j >> 1) & 1);
+        k.rdA = reinterpret_cast<const float4 *>(sw + 64 * j + ((8 * row) ^ fj));
+        k.rdB = reinterpret_cast<const float4 *>(sw + 64 * j + ((8 * row + 4) ^ fj));
+        const int grp = lane >> 3, r4 = grp >> 1;  // reduce-scatter placement as acc_slot(): row0 -> v0|v4, row1 -> v2|v6, row2 -> v1|v5, row3 -> v3|v7
+        k.acc = wAccF + 12 * j + ((r4 == 0) ? 0 : (r4 == 1) ? 2 : (r4 == 2) ? 1 : 3) + 4 * (grp & 1);
+        k.acc0 = wAccF + 12 * j + 8 + (lane >> 4);
+        k.pyrow = pyf - (float)(lane >> 3) + (float)row;  // = this lane's own pixel row
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int src = (lane & 56) + u;  // the lane whose pixel is (row, u)
+            k.dr[u] = __shfl(d0, src, 64);
+            k.dg[u] = __shfl(d1, src, 64);
+            k.db[u] = __shfl(d2, src, 64);
+            pxu[u] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pxf - (float)(lane & 7) + (float)u)));
+        }
+    }
 
     TileBwdState st;
     st.T = T_final; st.A = 0.f; st.touched = 0ull;
@@ -250,17 +316,17 @@ __global__ __launch_bounds__(64, 4) void k_composite_bwd_tiles(int W, int H, int
         st.touched = 0ull;
         {
             const f32x16 t0 = pow_tile_bf16(opA.a[0], opB.b[0]), t1 = pow_tile_bf16(opA.a[0], opB.b[1]);
-            if (0 < cnt) tiles_bwd_group<0>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
-            if (8 < cnt) tiles_bwd_group<1>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
-            if (16 < cnt) tiles_bwd_group<2>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
-            if (24 < cnt) tiles_bwd_group<3>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            if (0 < cnt) tiles_bwd_group<0>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (8 < cnt) tiles_bwd_group<1>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (16 < cnt) tiles_bwd_group<2>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (24 < cnt) tiles_bwd_group<3>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
         }
         if (32 < cnt) {
             const f32x16 t0 = pow_tile_bf16(opA.a[1], opB.b[0]), t1 = pow_tile_bf16(opA.a[1], opB.b[1]);
-            tiles_bwd_group<4>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
-            if (40 < cnt) tiles_bwd_group<5>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
-            if (48 < cnt) tiles_bwd_group<6>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
-            if (56 < cnt) tiles_bwd_group<7>(st, t0, t1, sXY, sCol, wAccF, lane, slot, pxf, pyf, topu, last, d0, d1, d2, nTb);
+            tiles_bwd_group<4>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (40 < cnt) tiles_bwd_group<5>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (48 < cnt) tiles_bwd_group<6>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (56 < cnt) tiles_bwd_group<7>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
         }
         wave_sync_lds();
         if ((st.touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 48-byte instance record (no atomics)
