@@ -202,8 +202,9 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
             const float om = 1.f - ae;
             const float rcp = __builtin_amdgcn_rcpf(om);
             st.T = st.T * rcp;
-            const float dL_dalpha = (cd - st.A) * st.T + nTb * rcp;
-            st.A = ae * cd + om * st.A;
+            const float cA = cd - st.A;
+            const float dL_dalpha = cA * st.T + nTb * rcp;
+            st.A = __builtin_fmaf(ae, cA, st.A);  // = ae cd + (1 - ae) A
             k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
             k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
         }
@@ -212,6 +213,7 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
     if ((st.touched >> (8 * GQ)) & 0xffull) tiles_bwd_phase2<GQ>(k, wXY, pxu, lane);
 }
 
+// 160 VGPRs: 3 waves per SIMD (2 and 3 measured identical: the kernel is VALU-issue bound; (64, 4) spills: 172 us)
 __global__ __launch_bounds__(64, 3) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
