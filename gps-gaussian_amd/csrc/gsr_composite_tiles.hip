@@ -38,7 +38,7 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
                 // upstream skips power > 0, which its own (PSD) quadratic form never produces.  The exact evaluation here can land one
                 // rounding above zero where the true exponent is 0 (splat centre on a pixel centre): such a pair is blended (exp2 of
                 // +1e-7 is 1 to fp32 precision), never skipped
-                const float alpha = fminf(0.99f, c.x * __builtin_amdgcn_exp2f(p[e]));
+                const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(p[e]));  // the tile holds log2(opacity G)
                 const lanemask_t valid = st.active & ~__ballot(alpha < 1.f / 255.f);
                 const float test_T = __builtin_fmaf(-alpha, st.T, st.T);  // T (1 - alpha), one rounding
                 const lanemask_t sat = __ballot(test_T < 0.0001f);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
     }
     for (uint32_t base = r0; base < r1; base += WAVE) {
         if (st.active == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
-        const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy));
+        const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy, gsr_log2_opacity(nB.y)));
         wave_sync_lds();  // previous round fully consumed
         sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
         wave_sync_lds();
@@ -175,6 +175,29 @@ __device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const fl
     if (!upper8) k.acc0[12 * 8 * GQ] = z;
 }
 
+// one staged splat of phase 1; inr = lanes whose pixel has this list position among its contributors
+__device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdConst &k, const float4 c, float pe, lanemask_t inr, int e, int j,
+                                               float dr, float dg, float db, float nTb) {
+    const float aG = __builtin_amdgcn_exp2f(pe);  // opacity * G (the tile holds its log2); as the forward: no power > 0 skip
+    const float alpha = fminf(0.99f, aG);
+    const lanemask_t valid_m = inr & ~__ballot(alpha < 1.f / 255.f);
+    if (valid_m != 0ull) {  // wave-uniform
+        st.touched |= 1ull << j;
+        const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+        const float cd = c.y * dr + c.z * dg + c.w * db;
+        const float ae = valid ? alpha : 0.f;
+        const float aGe = valid ? aG : 0.f;  // dalpha/dG * G = opacity * G, straight through the 0.99 clamp
+        const float om = 1.f - ae;
+        const float rcp = __builtin_amdgcn_rcpf(om);
+        st.T = st.T * rcp;
+        const float cA = cd - st.A;
+        const float dL_dalpha = cA * st.T + nTb * rcp;
+        st.A = __builtin_fmaf(ae, cA, st.A);  // = ae cd + (1 - ae) A
+        k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
+        k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
+    }
+}
+
 template <int GQ>
 __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wXY,
                                                 const float4 *__restrict__ wCol, const TileBwdConst &k, const float (&pxu)[8], int lane,
@@ -182,39 +205,23 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
     float p[8];
     pow_group8(d0, d1, GQ & 3, p);
     // {opacity, r, g, b} of staged splat j + 1 is fetched from LDS while splat j is processed (the load sits ahead of the wave-uniform
-    // skip branch and is consumed after it)
+    // skip branch and is consumed after it).  Staged slot j sits at list position top - j (slots beyond the front of the list: topu - j
+    // wraps to a huge position, and they carry opacity 0).
+    // (Tried: one in-range mask per group of 8 when its first and last position select the same lanes -- saves a compare per pair but
+    //  needs a second copy of the group body: 128 -> 159 us, instruction-cache bound.)
     float4 cn = wCol[8 * GQ];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        const int j = 8 * GQ + e;
-        const float4 c = cn;  // {opacity, r, g, b}
-        if (e < 7) cn = wCol[j + 1];
-        const float cd = c.y * dr + c.z * dg + c.w * db;
-        const float aG = c.x * __builtin_amdgcn_exp2f(p[e]);  // as the forward: no power > 0 skip
-        const float alpha = fminf(0.99f, aG);
-        // staged slot j sits at list position top - j (slots beyond the front of the list: topu - j wraps to a huge position, and they carry opacity 0)
-        const lanemask_t valid_m = __ballot(last > topu - (uint32_t)j) & ~__ballot(alpha < 1.f / 255.f);
-        if (valid_m != 0ull) {  // wave-uniform
-            st.touched |= 1ull << j;
-            const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
-            const float ae = valid ? alpha : 0.f;
-            const float aGe = valid ? aG : 0.f;  // dalpha/dG * G = opacity * G, straight through the 0.99 clamp
-            const float om = 1.f - ae;
-            const float rcp = __builtin_amdgcn_rcpf(om);
-            st.T = st.T * rcp;
-            const float cA = cd - st.A;
-            const float dL_dalpha = cA * st.T + nTb * rcp;
-            st.A = __builtin_fmaf(ae, cA, st.A);  // = ae cd + (1 - ae) A
-            k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
-            k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
-        }
+        const float4 c = cn;
+        if (e < 7) cn = wCol[8 * GQ + e + 1];
+        tiles_bwd_pair(st, k, c, p[e], __ballot(last > topu - (uint32_t)(8 * GQ + e)), e, 8 * GQ + e, dr, dg, db, nTb);
     }
     // splats of the group that no pixel touched leave stale numbers in their rows: their sums are never flushed (touched bit clear)
     if ((st.touched >> (8 * GQ)) & 0xffull) tiles_bwd_phase2<GQ>(k, wXY, pxu, lane);
 }
 
-// 160 VGPRs: 3 waves per SIMD (2 and 3 measured identical: the kernel is VALU-issue bound; (64, 4) spills: 172 us)
-__global__ __launch_bounds__(64, 3) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+// ~170 VGPRs: 2 waves per SIMD (2 and 3 measured identical: the kernel is VALU-issue bound; forcing 4 spills: 172 us)
+__global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(64, 3) void k_composite_bwd_tiles(int W, int H, int
     for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
         const int cnt = (int)min((int64_t)WAVE, top + 1);
         const uint32_t topu = (uint32_t)top;
-        const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy));
+        const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy, gsr_log2_opacity(nB.y)));
         wave_sync_lds();  // previous round fully consumed
         sXY[lane] = nA;
         sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(64) void k_selftest_tiles(float *__restrict__ out) 
     const float x = cx + (rnd(lane * 7 + 1) - 0.5f) * 30.f, y = cy + (rnd(lane * 7 + 2) - 0.5f) * 30.f;
     const float a = 0.02f + 3.3f * rnd(lane * 7 + 3), c = 0.02f + 3.3f * rnd(lane * 7 + 4), b = (rnd(lane * 7 + 5) - 0.5f) * 1.9f * sqrtf(a * c);
     sRec[lane][0] = x; sRec[lane][1] = y; sRec[lane][2] = a; sRec[lane][3] = b; sRec[lane][4] = c;
-    const PowOperandsA opA = pow_operands_a(pow_terms(x, y, a, b, c, cx, cy));
+    const PowOperandsA opA = pow_operands_a(pow_terms(x, y, a, b, c, cx, cy, 0.f));
     const PowOperandsB opB = pow_operands_b(lane);
 #pragma unroll
     for (int S = 0; S < 2; S++) {

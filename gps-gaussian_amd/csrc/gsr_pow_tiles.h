@@ -39,6 +39,9 @@ __device__ __forceinline__ void gsr_swap32(uint32_t a, uint32_t b, uint32_t &lo_
     lo_pair = r[0];
     hi_pair = r[1];
 }
+// log2(opacity) for pow_terms (v_log_f32: ~1 ulp, i.e. <= 5e-7 absolute for opacities >= 1/255); a slot without a splat (opacity 0) gets an
+// exponent that blends nothing
+__device__ __forceinline__ float gsr_log2_opacity(float op) { return op > 0.f ? __builtin_amdgcn_logf(op) : -150.f; }
 __device__ __forceinline__ float gsr_bf16_trunc(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 // two floats -> {bf16(first) in the low half, bf16(second) in the high half}, by truncation (v_perm_b32)
 __device__ __forceinline__ uint32_t gsr_pk_bf16(float first, float second) {
@@ -50,11 +53,12 @@ struct PowTerms {
     uint32_t t[2][8];
 };
 // k -> term:  MFMA 0: c0 c0 c0 cu cu cu cv cv | cv cuu cuu cuv cuv cvv cvv 0      MFMA 1: c0 c0 cu cu cv cv cuu cuu | cuv cuv cvv cvv 0 0 0 0
-__device__ __forceinline__ PowTerms pow_terms(float x, float y, float A, float B, float C, float cx, float cy) {
+// lop = log2(opacity) rides in the constant term: the tile then yields log2(opacity * G) and the blend loops start at alpha = min(0.99, exp2(.))
+__device__ __forceinline__ PowTerms pow_terms(float x, float y, float A, float B, float C, float cx, float cy, float lop) {
     const double X = (double)x - (double)cx, Y = (double)y - (double)cy;  // dx = x - px = X - u,  dy = Y - v
     const double a = (double)A * GSR_LOG2E_D, b = (double)B * GSR_LOG2E_D, c = (double)C * GSR_LOG2E_D;
     const double cu = a * X + b * Y, cv = b * X + c * Y;
-    const double coef[6] = {-0.5 * (X * cu + Y * cv), cu, cv, -0.5 * a, -b, -0.5 * c};
+    const double coef[6] = {(double)lop - 0.5 * (X * cu + Y * cv), cu, cv, -0.5 * a, -b, -0.5 * c};
     float p1[6], p2[6], p3[6], l1[6], l2[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
