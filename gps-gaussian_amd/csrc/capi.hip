@@ -128,11 +128,11 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     q.means3D = means3D; q.colors = colors; q.opacities = opacities; q.scales = scales; q.rotations = rotations;
     q.scale_modifier = scale_modifier; q.tanfovx = tanfovx; q.tanfovy = tanfovy;
     q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity;
-    // a workspace that includes the backward tail gets the per-Gaussian slot prefix and cleared inst_pos slots from the forward
+    // a workspace that includes the backward tail gets the per-Gaussian slot prefix and cleared record flags from the forward
     const bool training = workspace_bytes >= L.total;
     q.goff = training ? reinterpret_cast<uint32_t *>(at(workspace, L.goff)) : nullptr;
     q.gpart = training ? reinterpret_cast<uint32_t *>(at(workspace, L.gscan_part)) : nullptr;
-    uint32_t *inst_pos_fwd = training ? reinterpret_cast<uint32_t *>(at(workspace, L.inst_pos)) : nullptr;
+    uint8_t *inst_valid_fwd = training ? reinterpret_cast<uint8_t *>(at(workspace, L.inst_valid)) : nullptr;
     const int n_gblocks = (P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS;
 
     int rc;
@@ -149,7 +149,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_pos_fwd, s);
+        gsr_launch_scatter(P, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
@@ -199,19 +199,20 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     const uint32_t *n_contrib = reinterpret_cast<const uint32_t *>(at(workspace, L.n_contrib));
     uint32_t *goff = reinterpret_cast<uint32_t *>(at(workspace, L.goff));
     uint32_t *gscan_part = reinterpret_cast<uint32_t *>(at(workspace, L.gscan_part));
-    uint32_t *inst_pos = reinterpret_cast<uint32_t *>(at(workspace, L.inst_pos));
+    uint8_t *inst_valid = reinterpret_cast<uint8_t *>(at(workspace, L.inst_valid));
+    float *inst_dop = reinterpret_cast<float *>(at(workspace, L.inst_dop));
     GsrGradAcc *inst_grad = reinterpret_cast<GsrGradAcc *>(at(workspace, L.inst_grad));
 
-    // goff / gscan_part / cleared inst_pos slots were produced by the matching gsr_forward (training workspace)
+    // goff / gscan_part / cleared inst_valid were produced by the matching gsr_forward (training workspace)
     int rc;
     {
         StageTimer t(flags, GSR_STAGE_COMPOSITE_BWD, s);
         // must be the same family as the forward that filled the workspace: the two designs round the exponent differently, and the
         // backward has to repeat the forward's per-pixel decisions
         if (flags & GSR_FLAG_COMPOSITE_TILES)
-            gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_pos, inst_grad, hdr, s);
+            gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
         else
-            gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_pos, inst_grad, hdr, s);
+            gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     GsrBwdParams b;
@@ -223,7 +224,7 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
     {
         StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);
-        gsr_launch_preprocess_bwd(b, splats, goff, gscan_part, inst_pos, inst_grad, hdr, s);
+        gsr_launch_preprocess_bwd(b, splats, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
     }
     return check(s, flags);
 }

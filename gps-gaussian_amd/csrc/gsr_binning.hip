@@ -101,7 +101,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
                 if (k < n_gblocks) gpart[k] = carry + ex;
                 carry += tot;
             }
-            tot_slots = carry;  // inst_pos needs one slot per bin-rect cell (>= R: exact culling only removes instances)
+            tot_slots = carry;  // the gradient records need one slot per bin-rect cell (>= R: exact culling only removes instances)
         }
     };
     if (!FUSED) slot_scan();
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
                                                             const uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
                                                             const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
-                                                            const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos) {
+                                                            const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid) {
     if (hdr->overflow) return;
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t lo = 0, hi = 0, mask = 0;
@@ -202,15 +202,15 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, cons
                 const float4 a = rec[0], b = rec[1];
                 hit = gsr_hit_setup(a.x, a.y, a.z, a.w, b.x, b.y);
             }
-            if (inst_pos) {  // training: mark this Gaussian's instance slots "no record yet" (replaces a 4*cap-byte memset)
+            if (inst_valid) {  // training: "no gradient record yet" for every slot of this Gaussian (replaces a cap-byte memset)
                 const uint32_t s0 = gpart[i >> 10] + goff[i];
-                for (uint32_t k = 0; k < area; k++) inst_pos[s0 + k] = 0xffffffffu;
+                for (uint32_t k = 0; k < area; k++) inst_valid[s0 + k] = 0;
             }
         }
     }
     gsr_block_emit(
         wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS, lo, hi, bx, gsr_masked_hit(hit, mask, lo, hi), [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
-        [&](uint32_t pos) { keys[pos] = key; });
+        [&](uint32_t pos, uint32_t) { keys[pos] = key; });
 }
 
 // ascending compare-exchange on LDS / global arrays, virtual +inf padding beyond n (comparators with j >= n are no-ops)
@@ -426,10 +426,10 @@ void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *
 }
 
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s) {
+                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s) {
     if (P <= 0) return;
     hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr,
-                       goff, gpart, inst_pos);
+                       goff, gpart, inst_valid);
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,

@@ -23,13 +23,19 @@
 //   point_list[cap] u32 sorted gaussian ids (what the compositing kernels walk)
 //   final_T[H*W], n_contrib[H*W]                         per-pixel state kept for the backward
 //   --- backward-only tail (a forward-only caller may pass a workspace without it) ---
-//   goff[P], gscan_part[P/1024+1]   exclusive prefix of every Gaussian's bin-rect area (its slots in inst_pos), kept as
+//   goff[P], gscan_part[P/1024+1]   exclusive prefix of every Gaussian's bin-rect area (its slots in inst_valid / inst_grad), kept as
 //                  (prefix inside its 1024-block, prefix of the blocks): both fall out of the forward for free
-//   inst_pos[cap]  for (Gaussian, k-th bin of its rect): position of that instance in point_list, or ~0
-//   inst_grad[cap] 64-byte (48 used) records of per-INSTANCE partial sums {dcolor rgb, dmean2D xy | dconic xx xy yy, dopacity}
-//                  written with plain coalesced stores by the compositing backward and gathered per Gaussian by
-//                  k_preprocess_bwd: no float atomics at all (measured 20-30 Mops/ms on MI355X, tools/ubench/) and the
-//                  gradients are bit-reproducible run to run
+//   inst_valid[cap] one byte per (Gaussian, k-th cell of its bin rect) slot: cleared by k_scatter, set by the compositing backward
+//                  when it writes that instance's record
+//   inst_grad[cap] 32-byte records of per-INSTANCE partial sums {dcolor rgb, dmean2D xy, dconic xx xy yy}, GAUSSIAN-MAJOR (indexed by
+//                  slot); inst_dop[cap] the ninth sum (dopacity) as its own float array, so that a record is exactly one aligned
+//                  32-byte sector: a scattered store of a whole sector needs no merging and no read-modify-write (36-byte packed
+//                  records measured 113 MB written for 71 MB of payload).  No float atomics at all (measured 20-30 Mops/ms on
+//                  MI355X, tools/ubench/), gradients bit-reproducible run to run.  The compositing backward SCATTERS its records,
+//                  k_preprocess_bwd STREAMS them (a Gaussian's slots are contiguous, neighbouring threads own neighbouring slots).
+//                  The other way round -- records in sorted-list order, written coalesced and gathered per Gaussian -- made every
+//                  gather pull a 128-byte line for 48 useful bytes (measured: 253 MB fetched per launch against 127 MB
+//                  algorithmic): scattered READS are what costs on this memory system, scattered writes cost the sectors they touch.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,18 +58,16 @@ struct __attribute__((aligned(16))) GsrSplat {
 };
 static_assert(sizeof(GsrSplat) == 48, "splat record must be 48 bytes");
 
-struct __attribute__((aligned(64))) GsrGradAcc {
+struct __attribute__((aligned(32))) GsrGradAcc {
     float dr, dg, db, dmx;    // dL/dcolor, dL/dmean2D.x (NDC-scaled)
     float dmy, cxx, cxy, cyy; // dL/dmean2D.y, dL/dconic (xy holds HALF the true off-diagonal gradient, like upstream)
-    float dop, pad0, pad1, pad2;
-    float pad3[4];            // 64-byte records: the per-Gaussian gather then touches exactly one 64-byte sector per record
-};
-static_assert(sizeof(GsrGradAcc) == 64, "grad record must be 64 bytes");
+};                            // dL/dopacity lives in inst_dop[]
+static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte sector");
 
 struct GsrLayout {
     size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, hitmask, wg_tab, keys, point_list, final_T, n_contrib;
     size_t total_fwd;  // bytes a forward-only workspace needs
-    size_t goff, gscan_part, inst_pos, inst_grad, total;
+    size_t goff, gscan_part, inst_valid, inst_dop, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
     int bx, by;   // bin grid: bx = ceil(W/8) rounded up to a multiple of 4, by = ceil(H/8)
     int bx_real;  // ceil(W/8)
@@ -103,7 +107,8 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     L.total_fwd = o;
     L.goff = o;       o = gsr_align_up(o + (p + 1) * 4);
     L.gscan_part = o; o = gsr_align_up(o + (p / GSR_SCAN_BLOCK + 2) * 4);
-    L.inst_pos = o;   o = gsr_align_up(o + c * 4);
+    L.inst_valid = o; o = gsr_align_up(o + c);
+    L.inst_dop = o;   o = gsr_align_up(o + c * 4);
     L.inst_grad = o;  o = gsr_align_up(o + c * sizeof(GsrGradAcc));
     L.total = o;
     return L;
@@ -115,7 +120,8 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
 // atomics on the per-bin counters cost >100 us.  Pixel-Gaussians arrive in source-raster order, so the bins touched
 // by one 1024-thread workgroup form a small rectangle of the bin grid: the workgroup histograms its instances into a
 // direct-indexed LDS table over that rectangle (ds_add, which also hands every instance its rank) and then issues ONE
-// global atomic per touched bin (reserve(bin, count) -> base).  emit(pos) is called once per instance with its slot.
+// global atomic per touched bin (reserve(bin, count) -> base).  emit(pos, cell) is called once per instance with its slot
+// and the row-major index of the bin inside the Gaussian's own bin rect.
 // Incoherent input (bounding rectangle > GSR_BLOCK_TAB bins) falls back to one global atomic per instance.
 
 // Exact (Gaussian, bin) culling inside the bin rect.  alpha = op*exp(-q/2) >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2
@@ -227,7 +233,7 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
                 for (int x = x0; x < x1; x++) {
                     if (!hit(x, y)) continue;
                     const uint32_t pos = reserve(y * bx + x, 1u);
-                    if (EMIT) emit(pos);
+                    if (EMIT) emit(pos, (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
                 }
         return;
     }
@@ -254,7 +260,7 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
             for (int x = x0; x < x1; x++) {
                 if (!hit(x, y)) continue;
                 const int t = (y - by0) * bw + (x - bx0);
-                emit(s_base[t] + atomicAdd(&s_cnt[t], 1u));
+                emit(s_base[t] + atomicAdd(&s_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
             }
 }
 // Scatter pass from the recorded table: no bounding-box reduction, no table clearing, no counting loop -- one barrier.
@@ -285,7 +291,7 @@ __device__ __forceinline__ void gsr_block_emit(const uint32_t *tab, uint32_t lo,
             for (int x = x0; x < x1; x++) {
                 if (!hit(x, y)) continue;
                 const int t = (y - by0) * bw + (x - bx0);
-                emit(e_base[t] + atomicAdd(&e_cnt[t], 1u));
+                emit(e_base[t] + atomicAdd(&e_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
             }
 }
 #endif
@@ -308,14 +314,14 @@ void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
                      hipStream_t s);
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, hipStream_t s);
+                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s);
 void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
 void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
-                              const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, GsrGradAcc *inst_grad, const GsrHeader *hdr,
+                              const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop, GsrGradAcc *inst_grad, const GsrHeader *hdr,
                               hipStream_t s);
 // development knob: GPSGS_DEBUG_LDS_PAD=<bytes> of unused dynamic LDS per compositing workgroup (caps the waves resident per CU, to
 // measure how the kernels scale with occupancy); 0 / unset in normal use
@@ -330,7 +336,7 @@ void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat
                                     const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
-                                    const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos, GsrGradAcc *inst_grad, const GsrHeader *hdr,
+                                    const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop, GsrGradAcc *inst_grad, const GsrHeader *hdr,
                                     hipStream_t s);
 void gsr_launch_selftest(float *out4, hipStream_t s);
 struct GsrBwdParams {
@@ -342,4 +348,4 @@ struct GsrBwdParams {
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dscales, *dL_drotations;
 };
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
-                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s);
+                               const uint8_t *inst_valid, const float *inst_dop, const GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s);

@@ -117,8 +117,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
                                                        const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
-                                                       const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos, GsrGradAcc *__restrict__ inst_grad,
-                                                       const GsrHeader *__restrict__ hdr) {
+                                                       const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid, float *__restrict__ inst_dop,
+                                                       GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sA[WAVES][WAVE];
     __shared__ float4 sB[WAVES][WAVE];
     __shared__ float sC[WAVES][WAVE];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
     // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
     float nC = 0.f;
-    uint32_t nSlot = 0;  // where this lane's staged instance lives in its Gaussian's inst_pos slots
+    uint32_t nRec = 0;  // this lane's staged instance's slot (Gaussian, cell of its bin rect) = index of its gradient record
     const int bin_x = g.bin % bx, bin_y = g.bin / bx;
     auto stage = [&](uint32_t list_pos) {
         const uint32_t id = point_list[list_pos];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
         nC = c.x;
         const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
         const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-        nSlot = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
+        nRec = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
     };
     if ((int64_t)lane <= max_last - 1) stage(g.r0 + (uint32_t)(max_last - 1 - lane));
     for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
         wA[lane] = make_float4(nA.x, nA.y, -0.5f * GSR_LOG2E * nA.z, -GSR_LOG2E * nA.w);  // conic pre-scaled for gsr_power2 (as the forward)
         wB[lane] = make_float4(-0.5f * GSR_LOG2E * nB.x, nB.y, nB.z, nB.w);
         wC[lane] = nC;
-        const uint32_t curSlot = nSlot;
+        const uint32_t curRec = nRec;
         wave_sync_lds();
         const int64_t ntop = top - WAVE;
         if (ntop - lane >= 0) stage(g.r0 + (uint32_t)(ntop - lane));  // prefetch the next round
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
             if (slot >= 0) wAccF[12 * j + slot] = out;  // 12 lanes, 12 distinct words of this splat's record
         }
         wave_sync_lds();
-        if ((touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 48-byte instance record (no atomics)
+        if ((touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 32-byte instance record + its dL/dopacity (no atomics)
             const float4 v0 = wAcc[3 * lane], v1 = wAcc[3 * lane + 1], rs = wAcc[3 * lane + 2];
             const float4 sa = wA[lane], sb = wB[lane];  // this lane staged splat `lane` itself: conic (sa.z, sa.w, sb.x), opacity sb.y
             const float Sx = v0.w, Sy = v1.x, Sxx = v1.y, Sxy = v1.z, Syy = v1.w;
@@ -239,12 +239,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
             const float kA = 2.f / GSR_LOG2E, kB = 1.f / GSR_LOG2E;
             const float g_mx = ddelx_dx * (kA * sa.z * Sx + kB * sa.w * Sy);
             const float g_my = ddely_dy * (kA * sb.x * Sy + kB * sa.w * Sx);
-            const uint32_t p = g.r0 + (uint32_t)(top - lane);  // consecutive lanes -> consecutive records: coalesced
-            float4 *dst = reinterpret_cast<float4 *>(inst_grad + p);
+            // the record goes to the instance's SLOT (Gaussian-major; gsr_common.h)
+            float4 *dst = reinterpret_cast<float4 *>(inst_grad + curRec);  // one whole 32-byte sector
             dst[0] = make_float4(v0.x, v0.y, v0.z, g_mx);
             dst[1] = make_float4(g_my, -0.5f * Sxx, -0.5f * Sxy, -0.5f * Syy);
-            dst[2] = make_float4(S0 * __builtin_amdgcn_rcpf(sb.y), 0.f, 0.f, 0.f);
-            inst_pos[curSlot] = p;
+            inst_dop[curRec] = S0 * __builtin_amdgcn_rcpf(sb.y);
+            inst_valid[curRec] = 1;
         }
     }
 }
@@ -262,10 +262,10 @@ void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *spla
 
 void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
-                              const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos,
+                              const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop,
                               GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
     hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(64 * WAVES), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
-                       final_T, n_contrib, goff, gpart, inst_pos, inst_grad, hdr);
+                       final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }

@@ -226,8 +226,9 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
                                                             const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
-                                                            const uint32_t *__restrict__ gpart, uint32_t *__restrict__ inst_pos,
-                                                            GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
+                                                            const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid, float *__restrict__ inst_dop,
+                                                            GsrGradAcc *__restrict__ inst_grad,
+                                                            const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sXY[WAVE];       // {x, y, A, B} of the staged splats (x, y for the moments; A, B for the flush)
     __shared__ float4 sCol[WAVE];      // {opacity, r, g, b}
     __shared__ float4 sAcc[WAVE * 3];  // per staged splat: {dr,dg,db,Sx | Sy,Sxx,Sxy,Syy | 4 partial sums of S0}
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
     // positions are 0-based from the front of the bin list; walk from max_last-1 down to 0 in rounds of 64
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
     float nC = 0.f;
-    uint32_t nSlot = 0;  // where this lane's staged instance lives in its Gaussian's inst_pos slots
+    uint32_t nRec = 0;  // this lane's staged instance's slot (Gaussian, cell of its bin rect) = index of its gradient record
     const int bin_x = g.bin % bx, bin_y = g.bin / bx;
     auto stage = [&](int64_t pos) {
         nB.y = 0.f;  // a slot without a splat blends nothing (opacity 0)
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
             nC = c.x;
             const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-            nSlot = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
+            nRec = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
         }
     };
     stage(max_last - 1 - lane);
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
         sXY[lane] = nA;
         sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
         const float sC_ = nB.x, sop = nB.y;  // this lane's own staged splat, for the flush
-        const uint32_t curSlot = nSlot;
+        const uint32_t curRec = nRec;
         wave_sync_lds();
         stage(top - WAVE - lane);  // prefetch the next round
         st.touched = 0ull;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
             if (56 < cnt) tiles_bwd_group<7>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
         }
         wave_sync_lds();
-        if ((st.touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 48-byte instance record (no atomics)
+        if ((st.touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 32-byte instance record + its dL/dopacity (no atomics)
             const float4 v0 = sAcc[3 * lane], v1 = sAcc[3 * lane + 1], rs = sAcc[3 * lane + 2];
             const float4 sa = sXY[lane];  // this lane staged splat `lane` itself: conic A = sa.z, B = sa.w, C = sC_
             const float Sx = v0.w, Sy = v1.x, Sxx = v1.y, Sxy = v1.z, Syy = v1.w;
@@ -346,12 +347,13 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
             // dG/d(delta) = -G (A dx + B dy), -G (C dy + B dx);  dL/dconic = -0.5 s {dx^2, dx dy, dy^2};  dL/dop = G dL/dalpha = s / op
             const float g_mx = ddelx_dx * (-sa.z * Sx - sa.w * Sy);
             const float g_my = ddely_dy * (-sC_ * Sy - sa.w * Sx);
-            const uint32_t pp = r0 + (uint32_t)(top - lane);  // consecutive lanes -> consecutive records: coalesced
-            float4 *dst = reinterpret_cast<float4 *>(inst_grad + pp);
+            // the record goes to the instance's SLOT (Gaussian-major: scattered stores here, a streaming read in k_preprocess_bwd;
+            // scattered reads are what costs on this memory system, gsr_common.h)
+            float4 *dst = reinterpret_cast<float4 *>(inst_grad + curRec);  // one whole 32-byte sector
             dst[0] = make_float4(v0.x, v0.y, v0.z, g_mx);
             dst[1] = make_float4(g_my, -0.5f * Sxx, -0.5f * Sxy, -0.5f * Syy);
-            dst[2] = make_float4(S0 * __builtin_amdgcn_rcpf(sop), 0.f, 0.f, 0.f);
-            inst_pos[curSlot] = pp;
+            inst_dop[curRec] = S0 * __builtin_amdgcn_rcpf(sop);
+            inst_valid[curRec] = 1;
         }
     }
 }
@@ -423,12 +425,12 @@ void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat
 
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
-                                    const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint32_t *inst_pos,
+                                    const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop,
                                     GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
     hipLaunchKernelGGL(k_composite_bwd_tiles, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
-                       dL_dpix, final_T, n_contrib, goff, gpart, inst_pos, inst_grad, hdr);
+                       dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }
 
 void gsr_launch_selftest(float *out, hipStream_t s) { hipLaunchKernelGGL(k_selftest_tiles, dim3(1), dim3(64), 0, s, out); }

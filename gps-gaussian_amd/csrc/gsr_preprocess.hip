@@ -175,7 +175,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     dst[2] = make_float4(o2x, o2y, __uint_as_float(rlo), __uint_as_float(rhi));
     q.radii[i] = radius;
     }
-    if (q.goff) {  // training workspace: the slot prefix the backward needs (inst_pos slots = bin-rect cells) falls out here
+    if (q.goff) {  // training workspace: the slot prefix the backward needs (gradient-record slots = bin-rect cells) falls out here
         __shared__ uint32_t s_w[GSR_BIN_THREADS / 64];
         const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
         const int w = (int)(rhi & 0xffff) - (int)(rlo & 0xffff), h = (int)(rhi >> 16) - (int)(rlo >> 16);
@@ -210,18 +210,18 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
             if (h && k < 32) mask |= 1u << k;
             return h;
         },
-        [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t) {},
+        [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t, uint32_t) {},
         wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS);
     if (i < q.P) hitmask[i] = mask;
 }
 
 __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrSplat *__restrict__ splats,
                                                         const uint32_t *__restrict__ goff, const uint32_t *__restrict__ gpart,
-                                                        const uint32_t *__restrict__ inst_pos, const GsrGradAcc *__restrict__ inst_grad,
-                                                        const GsrHeader *__restrict__ hdr) {
+                                                        const uint8_t *__restrict__ inst_valid, const float *__restrict__ inst_dop,
+                                                        const GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= q.P) return;
-    // an overflowed forward rendered nothing: inst_pos / inst_grad were never written (and the slot range may not even fit the
+    // an overflowed forward rendered nothing: inst_valid / inst_grad were never written (and the slot range may not even fit the
     // workspace), so every Gaussian gets an exact zero gradient instead of a gather over garbage
     const bool rendered = hdr->overflow == 0u;
     float dm[3] = {0.f, 0.f, 0.f}, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -237,34 +237,34 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         // gather this Gaussian's instance records in rect order: fixed summation order -> reproducible gradients
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         float g2x = 0.f;
-        const float4 rc = reinterpret_cast<const float4 *>(splats + i)[2];
-        const uint32_t rlo = __float_as_uint(rc.z), rhi = __float_as_uint(rc.w);
-        const int rw = (int)(rhi & 0xffff) - (int)(rlo & 0xffff), rh = (int)(rhi >> 16) - (int)(rlo >> 16);
-        const uint32_t s0 = gpart[i >> 10] + goff[i], s1 = s0 + ((rw > 0 && rh > 0) ? (uint32_t)(rw * rh) : 0u);
+        // this Gaussian's slots [s0, s1): from the slot prefix alone (the splat record would cost a 48-byte-stride read for 8 bytes)
+        const int gb = i >> 10;
+        const uint32_t gbase = gpart[gb];
+        const uint32_t s0 = gbase + goff[i];
+        const uint32_t s1 = ((i & 1023) != 1023 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * 1024 < q.P ? gpart[gb + 1] : hdr->num_slots);
         for (uint32_t sl = s0; sl < s1; sl += 4) {
-            // 4 slots per step, branch-free: every load is unconditional (clamped index / record 0 as a harmless stand-in) so that
-            // all 4 position loads and then all 12 record loads are in flight together; what does not exist is dropped by a
-            // SELECT afterwards (never a multiply: the stand-in record may hold anything).  The predicated form made the
-            // compiler wait for each record before issuing the next gather.
-            uint32_t pi[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) pi[u] = inst_pos[min(sl + u, s1 - 1u)];
+            // 4 slots per step, branch-free: every load is unconditional (index clamped to this Gaussian's last slot) so that all 4
+            // flag and 12 record loads are in flight together; what does not exist is dropped by a SELECT afterwards (never a
+            // multiply: a slot without a record may hold anything).  The predicated form made the compiler wait for each record
+            // before issuing the next load.
             float4 a0[4], a1[4];
             float a2[4];
-            bool ok[4];
+            uint8_t vb[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                ok[u] = (sl + u < s1) && pi[u] != 0xffffffffu;
-                const float4 *r4 = reinterpret_cast<const float4 *>(inst_grad + (ok[u] ? pi[u] : 0u));
-                a0[u] = r4[0];
-                a1[u] = r4[1];
-                a2[u] = r4[2].x;
+                const uint32_t ri = min(sl + u, s1 - 1u);
+                const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri);
+                vb[u] = inst_valid[ri];
+                a0[u] = r[0];
+                a1[u] = r[1];
+                a2[u] = inst_dop[ri];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {  // fixed order: slot 0, 1, 2, 3 (adding +0 for a missing slot changes nothing)
-                g0.x += ok[u] ? a0[u].x : 0.f; g0.y += ok[u] ? a0[u].y : 0.f; g0.z += ok[u] ? a0[u].z : 0.f; g0.w += ok[u] ? a0[u].w : 0.f;
-                g1.x += ok[u] ? a1[u].x : 0.f; g1.y += ok[u] ? a1[u].y : 0.f; g1.z += ok[u] ? a1[u].z : 0.f; g1.w += ok[u] ? a1[u].w : 0.f;
-                g2x += ok[u] ? a2[u] : 0.f;
+                const bool ok = (sl + u < s1) && vb[u] != 0;
+                g0.x += ok ? a0[u].x : 0.f; g0.y += ok ? a0[u].y : 0.f; g0.z += ok ? a0[u].z : 0.f; g0.w += ok ? a0[u].w : 0.f;
+                g1.x += ok ? a1[u].x : 0.f; g1.y += ok ? a1[u].y : 0.f; g1.z += ok ? a1[u].z : 0.f; g1.w += ok ? a1[u].w : 0.f;
+                g2x += ok ? a2[u] : 0.f;
             }
         }
         const float4 g2 = make_float4(g2x, 0.f, 0.f, 0.f);
@@ -377,7 +377,8 @@ void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hi
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
-                               const uint32_t *inst_pos, const GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
+                               const uint8_t *inst_valid, const float *inst_dop, const GsrGradAcc *inst_grad, const GsrHeader *hdr,
+                               hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, goff, gpart, inst_pos, inst_grad, hdr);
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }
