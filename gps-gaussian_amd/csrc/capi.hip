@@ -143,7 +143,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCAN, s);
-        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
+        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, L.bx, L.by, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
                         (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;

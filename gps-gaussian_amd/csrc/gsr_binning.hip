@@ -21,6 +21,18 @@ namespace {
 
 constexpr int SB = GSR_SCAN_BLOCK;  // 1024 bins per scan block
 
+// Work order of the compositing / sorting waves: the bin grid enumerated in PATCHES of 8x8 bins (64x64 pixels; row-major inside a
+// patch, patches row-major).  A Gaussian is listed in ~3 neighbouring bins, mostly a 2x2 block: in this order the block's bins are
+// (with probability ~0.77) within 64 consecutive entries, which xcd_list_pos() hands to ONE XCD -- one L2 then fetches the splat
+// record once for all of them and merges the gradient records the compositing backward scatters into the Gaussian's (contiguous)
+// slots.  Image order (runs of 64x1 bins) shared only the horizontal neighbours.  -1: the index has no bin (ragged grid edge).
+__device__ __forceinline__ int tiled_bin(uint32_t t, int bx, int by) {
+    const uint32_t pgx = ((uint32_t)bx + 7u) >> 3;
+    const uint32_t p = t >> 6, w = t & 63u;
+    const uint32_t x = (p % pgx) * 8u + (w & 7u), y = (p / pgx) * 8u + (w >> 3);
+    return (x < (uint32_t)bx && y < (uint32_t)by) ? (int)(y * (uint32_t)bx + x) : -1;
+}
+
 // block-wide exclusive scan of one uint per thread (1024 threads); returns the exclusive prefix, *total = block sum
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum /*[16]*/, uint32_t *total) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -44,13 +56,16 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum /*[1
     return woff + x - v;
 }
 
-// phase A: per block of 1024 bins -> {sum of counts, number of busy compositing workgroups, max count}
-__global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part, int NB) {
+// phase A: per block of 1024 indices -> {sum of counts (bins in image order), busy | idle << 16 bins among the block's indices in
+// WORK order (tiled_bin), max count}
+__global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part, int NB, int bx, int by) {
     __shared__ uint32_t red[3][SB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x * SB + tid;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
-    const uint32_t busy = c > 0 ? 1u : 0u;  // one compositing workgroup (= one wave) per bin
+    const int wb = tiled_bin((uint32_t)b, bx, by);
+    const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] : 0u;
+    const uint32_t busy = wc > 0 ? 1u : (wb >= 0 ? 0x10000u : 0u);  // one compositing workgroup (= one wave) per bin
     uint32_t s = c, nb = busy, mx = c;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_
 template <bool FUSED>
 __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part,
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
-                                               uint32_t *__restrict__ wg_order, int NB, int nblocks, int64_t cap,
+                                               uint32_t *__restrict__ wg_order, int NB, int bx, int by, int nblocks, int64_t cap,
                                                GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
                                                uint32_t *__restrict__ host_hdr, uint32_t host_seq, int no_large_sort) {
     __shared__ uint32_t wsum[SB / 64];
@@ -86,6 +101,8 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     const int tid = threadIdx.x;
     const int b = blockIdx.x * SB + tid;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
+    const int wb = tiled_bin((uint32_t)b, bx, by);  // the bin this thread places in the work order
+    const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] : 0u;
     // block 0 also owns the per-Gaussian slot prefix (training) and the header.  Neither depends on the other blocks' bins, so the
     // slot scan runs first -- under the wait for their partials -- and the header leaves (also towards the host) as soon as the
     // totals are known, before this block scans its own bins.
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     if (FUSED) {
         __shared__ uint32_t red[3][SB / 64];
         const int lane = tid & 63, wid = tid >> 6;
-        uint32_t s = c, nb = c > 0 ? 1u : 0u, mx = c;
+        uint32_t s = c, nb = wc > 0 ? 1u : (wb >= 0 ? 0x10000u : 0u), mx = c;  // nb: busy | idle << 16 (each <= 1024)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             s += __shfl_xor(s, d, 64);
@@ -135,12 +152,12 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         }
         __syncthreads();
     }
-    uint32_t pre_sum = 0, pre_busy = 0, tot_busy = 0, tot_max = 0;
+    uint32_t pre_sum = 0, pre_busy = 0, pre_idle = 0, tot_busy = 0, tot_max = 0;
     uint64_t tot_sum = 0;  // 64-bit: a total beyond 2^32 must read as an overflow, not wrap below the capacity
     for (int i = 0; i < nblocks; i++) {  // a handful of uint4
         const uint4 p = FUSED ? sp[i] : part[i];
-        if (i < (int)blockIdx.x) { pre_sum += p.x; pre_busy += p.y; }
-        tot_sum += p.x; tot_busy += p.y; tot_max = p.z > tot_max ? p.z : tot_max;
+        if (i < (int)blockIdx.x) { pre_sum += p.x; pre_busy += p.y & 0xffffu; pre_idle += p.y >> 16; }
+        tot_sum += p.x; tot_busy += p.y & 0xffffu; tot_max = p.z > tot_max ? p.z : tot_max;
     }
     if (blockIdx.x == 0 && tid == 0) {
         bin_offset[NB] = (uint32_t)tot_sum;
@@ -168,16 +185,11 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         bin_offset[b] = off;
         bin_cursor[(size_t)b * GSR_CPAD] = off;
     }
-    // work-ordered workgroup list
-    const bool is_wg_lead = b < NB;
-    const bool busy = is_wg_lead && c > 0;
-    uint32_t blk_busy;
-    const uint32_t bpos = block_exscan(busy ? 1u : 0u, wsum, &blk_busy);
-    if (is_wg_lead) {
-        const uint32_t w = (uint32_t)b / GSR_BINS_PER_WG;
-        const uint32_t nbusy_before = pre_busy + bpos;
-        wg_order[busy ? nbusy_before : tot_busy + (w - nbusy_before)] = w;
-    }
+    // work-ordered workgroup list: busy bins first, in patch order (tiled_bin) inside each class; both ranks from one scan
+    const bool busy = wc > 0;
+    uint32_t blk_tot;
+    const uint32_t rank = block_exscan(busy ? 1u : (wb >= 0 ? 0x10000u : 0u), wsum, &blk_tot);
+    if (wb >= 0) wg_order[busy ? pre_busy + (rank & 0xffffu) : tot_busy + pre_idle + (rank >> 16)] = (uint32_t)wb;
 }
 
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
@@ -411,17 +423,18 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 
 }  // namespace
 
-void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
+void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
                      hipStream_t s) {
-    const int nblocks = (NB + SB - 1) / SB;
+    const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB: ragged patches at the grid edge)
+    const int nblocks = ((NT > NB ? NT : NB) + SB - 1) / SB;
     if (nblocks <= GSR_SCAN_FUSE_MAX) {
-        hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap,
+        hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap,
                            hdr, gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0);
         return;
     }
-    hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB);
-    hipLaunchKernelGGL(k_scan_b<false>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, nblocks, cap, hdr,
+    hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB, bx, by);
+    hipLaunchKernelGGL(k_scan_b<false>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap, hdr,
                        gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0);
 }
 

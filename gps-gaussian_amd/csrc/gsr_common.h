@@ -73,7 +73,7 @@ struct GsrLayout {
     int bx_real;  // ceil(W/8)
     int NB;       // bx * by
     int NWG;      // NB / GSR_BINS_PER_WG compositing workgroups
-    int NSB;      // scan blocks = ceil(NB / GSR_SCAN_BLOCK)
+    int NSB;      // scan blocks = ceil(max(NB, indices of the patch work order) / GSR_SCAN_BLOCK)
 };
 
 static inline size_t gsr_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -87,7 +87,10 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     L.by = (H + GSR_BIN - 1) / GSR_BIN;
     L.NB = L.bx * L.by;
     L.NWG = L.NB / GSR_BINS_PER_WG;
-    L.NSB = (L.NB + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
+    {
+        const int nt = ((L.bx + 7) / 8) * ((L.by + 7) / 8) * 64;  // gsr_binning.hip: tiled_bin()
+        L.NSB = ((nt > L.NB ? nt : L.NB) + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
+    }
     size_t o = 0;
     const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.NB > 0 ? L.NB : 1), c = (size_t)(cap > 0 ? cap : 1);
     const size_t npix = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
@@ -310,7 +313,7 @@ struct GsrFwdParams {
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
                            hipStream_t s);
-void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB,
+void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
                      hipStream_t s);
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,

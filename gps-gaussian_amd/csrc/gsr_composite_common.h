@@ -15,13 +15,13 @@ struct WaveGeom {
     uint32_t r0, r1;
 };
 
-// Position in the work-ordered list (busy bins first, row-major) this workgroup takes.  Workgroups are handed to the 8 XCDs
-// round-robin (workgroup w -> XCD w % 8) and every XCD has its own L2, while a Gaussian is listed in ~3 NEIGHBOURING bins:
-// taking the list in dispatch order would put neighbours on different XCDs and every XCD would fetch its own copy of the
-// shared splat records from HBM (measured: 2.2x the fetch traffic).  Instead the busy list is cut into runs of 64 consecutive
-// bins (half an image row at 1024^2) that are dealt to the XCDs in turn: neighbours along a row share one L2, and every XCD
-// still gets runs from all over the image (one contiguous eighth per XCD cut the traffic further but left the XCDs unevenly
-// loaded: +3 % time).  The map is a bijection on [0, 512 * ceil(busy / 512)); idle bins behind it keep their place.
+// Position in the work-ordered list (busy bins first, in patches of 8x8 bins: gsr_binning.hip tiled_bin) this workgroup takes.
+// Workgroups are handed to the 8 XCDs round-robin (workgroup w -> XCD w % 8) and every XCD has its own L2, while a Gaussian is listed
+// in ~3 NEIGHBOURING bins: taking the list in dispatch order would put neighbours on different XCDs and every XCD would fetch its own
+// copy of the shared splat records (measured: 2.2x the fetch traffic).  Instead the busy list is cut into runs of 64 consecutive
+// entries (about one 64x64-pixel patch) that are dealt to the XCDs in turn: the neighbours of a bin in BOTH directions share one L2,
+// and every XCD still gets runs from all over the image (one contiguous eighth per XCD cut the traffic further but left the XCDs
+// unevenly loaded: +3 % time).  The map is a bijection on [0, 512 * ceil(busy / 512)); idle bins behind it keep their place.
 // (If that range does not fit the grid -- tiny images -- keep the identity.)
 __device__ __forceinline__ uint32_t xcd_list_pos(uint32_t w, uint32_t busy) {
     const uint32_t span = ((busy + 511u) >> 9) << 9;
