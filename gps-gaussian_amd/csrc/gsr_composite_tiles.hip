@@ -149,9 +149,11 @@ __device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const fl
     const float2 xy = *reinterpret_cast<const float2 *>(&wXY[8 * GQ + (lane & 7)]);
     const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-    float S0 = 0.f, Sx = 0.f, Sxx = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    // the sums start from the u = 0 terms (0 + x and fma(a, b, 0) are not folded by the compiler: -0 semantics; same bits)
+    const float dx0 = xy.x - pxu[0], mx0 = sv[0] * dx0;
+    float S0 = sv[0], Sx = mx0, Sxx = mx0 * dx0, cr = wv[0] * k.dr[0], cg = wv[0] * k.dg[0], cb = wv[0] * k.db[0];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 1; u < 8; u++) {
         const float dx = xy.x - pxu[u];  // the same single rounding as x - (float)px
         const float mx = sv[u] * dx;
         S0 += sv[u];
@@ -179,14 +181,15 @@ __device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const fl
 __device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdConst &k, const float4 c, float pe, lanemask_t inr, int e, int j,
                                                float dr, float dg, float db, float nTb) {
     const float aG = __builtin_amdgcn_exp2f(pe);  // opacity * G (the tile holds its log2); as the forward: no power > 0 skip
-    const float alpha = fminf(0.99f, aG);
-    const lanemask_t valid_m = inr & ~__ballot(alpha < 1.f / 255.f);
+    // the forward's test alpha = min(0.99, aG) < 1/255 is aG < 1/255: the clamp is applied after the select (one select instead of two)
+    const lanemask_t valid_m = inr & ~__ballot(aG < 1.f / 255.f);
     if (valid_m != 0ull) {  // wave-uniform
         st.touched |= 1ull << j;
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
-        const float cd = c.y * dr + c.z * dg + c.w * db;
-        const float ae = valid ? alpha : 0.f;
+        const float cd = c.x * dr + c.y * dg + c.z * db;
         const float aGe = valid ? aG : 0.f;  // dalpha/dG * G = opacity * G, straight through the 0.99 clamp
+        float ae;  // min(0.99, aGe) as ONE v_min_f32 (fminf() first canonicalises the select's result: a wasted v_max)
+        __asm__("v_min_f32_e32 %0, 0x3f7d70a4, %1" : "=v"(ae) : "v"(aGe));
         const float om = 1.f - ae;
         const float rcp = __builtin_amdgcn_rcpf(om);
         st.T = st.T * rcp;
@@ -204,7 +207,7 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
                                                 uint32_t topu, uint32_t last, float dr, float dg, float db, float nTb) {
     float p[8];
     pow_group8(d0, d1, GQ & 3, p);
-    // {opacity, r, g, b} of staged splat j + 1 is fetched from LDS while splat j is processed (the load sits ahead of the wave-uniform
+    // {r, g, b} of staged splat j + 1 is fetched from LDS while splat j is processed (the load sits ahead of the wave-uniform
     // skip branch and is consumed after it).  Staged slot j sits at list position top - j (slots beyond the front of the list: topu - j
     // wraps to a huge position, and they carry opacity 0).
     // (Tried: one in-range mask per group of 8 when its first and last position select the same lanes -- saves a compare per pair but
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
                                                             GsrGradAcc *__restrict__ inst_grad,
                                                             const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sXY[WAVE];       // {x, y, A, B} of the staged splats (x, y for the moments; A, B for the flush)
-    __shared__ float4 sCol[WAVE];      // {opacity, r, g, b}
+    __shared__ float4 sCol[WAVE];      // {r, g, b, -}: colour first, so that one aligned ds_read_b96 (immediate offset) fetches it
     __shared__ float4 sAcc[WAVE * 3];  // per staged splat: {dr,dg,db,Sx | Sy,Sxx,Sxy,Syy | 4 partial sums of S0}
     __shared__ float4 sSW[2 * TILE_SW_WORDS / 4];  // phase 1 -> phase 2: s[8 splats][64 pixels], w[8][64], rows XOR-swizzled
     if (hdr->overflow) return;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
         const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy, gsr_log2_opacity(nB.y)));
         wave_sync_lds();  // previous round fully consumed
         sXY[lane] = nA;
-        sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
+        sCol[lane] = make_float4(nB.z, nB.w, nC, 0.f);
         const float sC_ = nB.x, sop = nB.y;  // this lane's own staged splat, for the flush
         const uint32_t curRec = nRec;
         wave_sync_lds();
