@@ -417,6 +417,45 @@ def test_backward_is_bit_reproducible():
         np.testing.assert_array_equal(g1[k], g2[k])
 
 
+def test_stale_gradient_records_of_an_earlier_view_are_never_read():
+    """The per-instance gradient records live in slots that belong to (Gaussian, cell of its bin rect) and are reused from view to
+    view; a flag byte per slot -- cleared by k_scatter, set by the compositing backward -- says whether THIS backward wrote the
+    slot.  Rendering B, then a different scene A of the same sizes (same recycled workspace memory: A's records now sit in the
+    slots), then B again must give B's gradients bit for bit; so must a second backward over one forward (flags already set)."""
+    import torch
+    from gps_gaussian_amd import synthetic as S
+    from gps_gaussian_amd import rasterizer as RZ
+    W = H = 200
+    gB = S.make_uniform_cloud(6000, W, H, seed=71, scale_med=0.02, z_range=(0.5, 3.0), behind_frac=0.05)
+    gA = S.make_uniform_cloud(6000, W, H, seed=72, scale_med=0.05, z_range=(0.4, 2.0), behind_frac=0.0)
+    gA["opacities"][:] = 0.95  # opaque front layers: many of A's slots are touched where B's are not, and the other way round
+    dpix = np.random.default_rng(7).standard_normal((3, H, W)).astype(np.float32)
+    _, _, g1, _ = hip_render(gB, dpix)
+    hip_render(gA, dpix)
+    _, _, g2, _ = hip_render(gB, dpix)
+    for k in g1:
+        np.testing.assert_array_equal(g1[k], g2[k])
+    # two backwards over ONE forward
+    dev = torch.device("cuda:0")
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    t = {k: torch.from_numpy(np.ascontiguousarray(gB[k], dtype=np.float32)).to(dev).requires_grad_(True) for k in names}
+    m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+    rs = RZ.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=gB["tanfovx"], tanfovy=gB["tanfovy"], bg=torch.from_numpy(gB["bg"]).to(dev),
+                                          scale_modifier=1.0, viewmatrix=torch.from_numpy(gB["view"]).to(dev), projmatrix=torch.from_numpy(gB["proj"]).to(dev),
+                                          sh_degree=3, campos=torch.from_numpy(gB["campos"]).to(dev), prefiltered=False, debug=False)
+    img, _ = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=None, colors_precomp=t["colors"], opacities=t["opacities"],
+                                       scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    d = torch.from_numpy(dpix).to(dev)
+    img.backward(d, retain_graph=True)
+    first = {k: t[k].grad.clone() for k in names}
+    for k in names:
+        t[k].grad = None
+    img.backward(d)
+    for k in names:
+        assert torch.equal(first[k], t[k].grad), k
+        np.testing.assert_array_equal(first[k].cpu().numpy(), g1[k])
+
+
 _FUZZ = [  # (W, H, P, seed, scale_med, z_range, behind_frac)
     (1, 1, 1, 1, 0.05, (0.5, 2.0), 0.0), (7, 9, 3, 2, 0.05, (0.5, 2.0), 0.0), (8, 8, 64, 3, 0.02, (0.5, 3.0), 0.1),
     (9, 7, 200, 4, 0.01, (0.3, 3.0), 0.1), (16, 16, 1, 5, 0.5, (1.0, 1.5), 0.0), (17, 33, 500, 6, 0.03, (0.5, 6.0), 0.05),
