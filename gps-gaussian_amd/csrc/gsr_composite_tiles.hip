@@ -10,6 +10,8 @@
 // v_exp_f32: the 8 VALU instructions per (pixel, splat) pair that computed dx, dy and the quadratic form are gone (forward 23 -> 15
 // per pair), for ~1.7 instructions per (bin, splat) of operand preparation and 4 cycles per (bin, splat) on the matrix pipe.
 // The backward's pair body needs no dx, dy either: its sums over the pixels are formed in a second phase with lane = (splat, pixel row).
+#include <type_traits>
+
 #include "gsr_pow_tiles.h"
 
 namespace {
@@ -177,7 +179,9 @@ __device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const fl
     if (!upper8) k.acc0[12 * 8 * GQ] = z;
 }
 
-// one staged splat of phase 1; inr = lanes whose pixel has this list position among its contributors
+// one staged splat of phase 1; inr = lanes whose pixel has this list position among its contributors.  BG = false: the background is
+// black (the reference's stage 2, config/stereo_human_config.py:24), its term of dL/dalpha is an exact zero and is left out
+template <bool BG>
 __device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdConst &k, const float4 c, float pe, lanemask_t inr, int e, int j,
                                                float dr, float dg, float db, float nTb) {
     const float aG = __builtin_amdgcn_exp2f(pe);  // opacity * G (the tile holds its log2); as the forward: no power > 0 skip
@@ -194,14 +198,14 @@ __device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdCo
         const float rcp = __builtin_amdgcn_rcpf(om);
         st.T = st.T * rcp;
         const float cA = cd - st.A;
-        const float dL_dalpha = cA * st.T + nTb * rcp;
+        const float dL_dalpha = BG ? cA * st.T + nTb * rcp : cA * st.T;
         st.A = __builtin_fmaf(ae, cA, st.A);  // = ae cd + (1 - ae) A
         k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
         k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
     }
 }
 
-template <int GQ>
+template <int GQ, bool BG>
 __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wXY,
                                                 const float4 *__restrict__ wCol, const TileBwdConst &k, const float (&pxu)[8], int lane,
                                                 uint32_t topu, uint32_t last, float dr, float dg, float db, float nTb) {
@@ -217,7 +221,7 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
     for (int e = 0; e < 8; e++) {
         const float4 c = cn;
         if (e < 7) cn = wCol[8 * GQ + e + 1];
-        tiles_bwd_pair(st, k, c, p[e], __ballot(last > topu - (uint32_t)(8 * GQ + e)), e, 8 * GQ + e, dr, dg, db, nTb);
+        tiles_bwd_pair<BG>(st, k, c, p[e], __ballot(last > topu - (uint32_t)(8 * GQ + e)), e, 8 * GQ + e, dr, dg, db, nTb);
     }
     // splats of the group that no pixel touched leave stale numbers in their rows: their sums are never flushed (touched bit clear)
     if ((st.touched >> (8 * GQ)) & 0xffull) tiles_bwd_phase2<GQ>(k, wXY, pxu, lane);
@@ -315,6 +319,9 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
         }
     };
     stage(max_last - 1 - lane);
+    // the walk exists twice (generic lambda, instantiated per background class); one launch only ever runs one of the two
+    auto walk = [&](auto bg_tag) {
+    constexpr bool BG = decltype(bg_tag)::value;
     for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
         const int cnt = (int)min((int64_t)WAVE, top + 1);
         const uint32_t topu = (uint32_t)top;
@@ -329,17 +336,17 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
         st.touched = 0ull;
         {
             const f32x16 t0 = pow_tile_bf16(opA.a[0], opB.b[0]), t1 = pow_tile_bf16(opA.a[0], opB.b[1]);
-            if (0 < cnt) tiles_bwd_group<0>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (8 < cnt) tiles_bwd_group<1>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (16 < cnt) tiles_bwd_group<2>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (24 < cnt) tiles_bwd_group<3>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (0 < cnt) tiles_bwd_group<0, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (8 < cnt) tiles_bwd_group<1, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (16 < cnt) tiles_bwd_group<2, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (24 < cnt) tiles_bwd_group<3, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
         }
         if (32 < cnt) {
             const f32x16 t0 = pow_tile_bf16(opA.a[1], opB.b[0]), t1 = pow_tile_bf16(opA.a[1], opB.b[1]);
-            tiles_bwd_group<4>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (40 < cnt) tiles_bwd_group<5>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (48 < cnt) tiles_bwd_group<6>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (56 < cnt) tiles_bwd_group<7>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            tiles_bwd_group<4, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (40 < cnt) tiles_bwd_group<5, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (48 < cnt) tiles_bwd_group<6, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (56 < cnt) tiles_bwd_group<7, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
         }
         wave_sync_lds();
         if ((st.touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 32-byte instance record + its dL/dopacity (no atomics)
@@ -359,6 +366,10 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
             inst_valid[curRec] = 1;
         }
     }
+    };
+    const bool black = __builtin_amdgcn_readfirstlane((int)(bg[0] == 0.f && bg[1] == 0.f && bg[2] == 0.f)) != 0;
+    if (black) walk(std::false_type{});
+    else walk(std::true_type{});
 }
 
 // ---- device self-test of the tile plumbing (gsr_selftest): the SAME device functions the kernels use, on pseudo-random splats
