@@ -91,7 +91,7 @@ def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, st
     el = timed(step, steps, 2)
     return {"iters_per_s": round(steps / el, 2), "stereo_pairs_per_s": round(world * batch * steps / el, 1), "ms_per_iter": round(el / steps * 1e3, 3),
             "batch_per_gpu": batch, "n_gpus": world, "render": "%dx%d" % (rres, rres),
-            "includes": "pts2render (fused pack + %d raster forwards) + L1/SSIM loss + backward to the per-pixel maps + mean all-reduce of "
+            "includes": "pts2render (fused pack + %d raster forwards as one autograd node, one HIP stream per sample) + L1/SSIM loss + backward to the per-pixel maps + mean all-reduce of "
                         "20.6 MB of network gradients (RCCL); networks not executed" % batch}
 
 

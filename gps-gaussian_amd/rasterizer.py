@@ -24,6 +24,7 @@ Host-side design notes (MI355X-first, not a translation of upstream's C++ glue):
 """
 import ctypes as C
 import os
+import threading
 from typing import NamedTuple
 
 import torch
@@ -66,12 +67,14 @@ def set_stage_timing(on, stage=None):
 _MIN_CAP = 1 << 16
 _early_notify = os.environ.get("GPSGS_EARLY_NOTIFY", "1") != "0"  # 0: sync mode waits for the whole forward (event after a header copy)
 _state = {}  # device index -> dict(ratio=instances per Gaussian seen so far, pending=[(event, pinned_header, P)])
+_lock = threading.Lock()  # the per-device capacity state and the pinned header rings may be used from several host threads
 
 
 def _dev_state(dev):
     st = _state.get(dev.index)
     if st is None:
-        st = _state[dev.index] = dict(ratio=4.0, floor=_MIN_CAP, pending=[])
+        with _lock:
+            st = _state.setdefault(dev.index, dict(ratio=4.0, floor=_MIN_CAP, pending=[]))
     return st
 
 
@@ -127,10 +130,11 @@ def _decode(hdr):
 
 
 def _learn(st, R, need, P):
-    st["last_R"] = R
-    if P > 0:
-        st["ratio"] = max(st["ratio"], need / P)
-    st["floor"] = max(st["floor"], min(int(need * 1.25) + 4096, 0x7fffffff))
+    with _lock:  # read-modify-write of monotone maxima
+        st["last_R"] = R
+        if P > 0:
+            st["ratio"] = max(st["ratio"], need / P)
+        st["floor"] = max(st["floor"], min(int(need * 1.25) + 4096, 0x7fffffff))
 
 
 def _ptr(t):
@@ -151,16 +155,18 @@ class _HeaderRing:
         self.seq = 0
 
     def next(self):
-        i = self.i
-        self.i = (i + 1) % self.n
+        with _lock:
+            i = self.i
+            self.i = (i + 1) % self.n
         return self.np[i], C.c_void_p(self.base + 32 * i), self.events[i]
 
     def next_notify(self):
         """-> (int64[4] header view, uint32[8] view, pointer, sequence number the device will store in word 7)."""
-        i = self.i
-        self.i = (i + 1) % self.n
-        self.seq = self.seq % 0x7fffffff + 1  # never 0, never equal to what the slot holds from its previous use
-        return self.np[i], self.np32[i], C.c_void_p(self.base + 32 * i), self.seq
+        with _lock:  # slot and sequence number are handed out together: two host threads never share either
+            i = self.i
+            self.i = (i + 1) % self.n
+            seq = self.seq = self.seq % 0x7fffffff + 1  # never 0, never equal to what the slot holds from its previous use
+        return self.np[i], self.np32[i], C.c_void_p(self.base + 32 * i), seq
 
 
 def _wait_notify(w32, seq, cur_stream):
@@ -208,7 +214,9 @@ def _ring(dev, kind="notify"):
     kind can so never be handed out while the other path still has it in flight."""
     r = _rings.get((dev.index, kind))
     if r is None:
-        r = _rings[(dev.index, kind)] = _HeaderRing()
+        ring = _HeaderRing()  # (allocates pinned memory: outside the lock)
+        with _lock:
+            r = _rings.setdefault((dev.index, kind), ring)
     return r
 
 
@@ -259,138 +267,196 @@ def _device_guard(dev):
     return _NOGUARD if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
+def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, needs_grad, out_color=None):
+    """One view's forward through the C-ABI (capacity policy, early notification, overflow repair).  `ctx` is any attribute holder: the
+    autograd ctx of _RasterizeGaussians, or a plain namespace when a caller drives several views itself (render_api._RenderBatch).
+    Leaves on it: raster_settings, cap, family, saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws) and, inside
+    defer_capacity_checks(), ws_box.  out_color: optional preallocated contiguous fp32 [3,H,W] the image is written into.
+    -> (color, radii)"""
+    rs = raster_settings
+    lib = _capi.lib()
+    if not means3D.is_cuda:
+        raise RuntimeError("gps_gaussian_amd: rasteriser inputs must live on a GPU (no CPU fallback)")
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    m3 = _prep(means3D, "means3D", (3,), dev)
+    col = _prep(colors_precomp, "colors_precomp", (3,), dev)
+    opa = _prep(opacities, "opacities", None, dev).reshape(-1)
+    sca = _prep(scales, "scales", (3,), dev)
+    rot = _prep(rotations, "rotations", (4,), dev)
+    if not (col.shape[0] == opa.shape[0] == sca.shape[0] == rot.shape[0] == P):
+        raise RuntimeError("all per-Gaussian inputs must have num_points rows")
+    view = _cam(rs.viewmatrix, 16, dev)
+    proj = _cam(rs.projmatrix, 16, dev)
+    bg = _cam(rs.bg, 3, dev)
+    family = _composite_flag()
+    flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | family
+    mode = _check_mode()
+    st = _dev_state(dev)
+    if mode != "none" and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("gps_gaussian_amd: the capacity check reads a header back on the host and cannot run under graph capture; "
+                           "warm up eagerly, then capture with GPSGS_CHECK=none")
+    with _device_guard(dev):
+        if mode != "none":
+            _drain_pending(st)
+        cur_stream = torch.cuda.current_stream(dev)
+        stream = cur_stream.cuda_stream
+        ring = _ring(dev)
+        if out_color is None:
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        else:
+            color = out_color
+            if (color.dtype is not torch.float32 or color.device != dev or tuple(color.shape) != (3, H, W) or not color.is_contiguous()):
+                raise RuntimeError("gps_gaussian_amd: out_color must be a contiguous fp32 [3, H, W] tensor on the inputs' device")
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        cap = _capacity_for(st, P)
+        # inference (no input needs a gradient): skip the backward tail of the workspace (37 B per instance slot)
+        ws_bytes = lib.gsr_workspace_bytes if needs_grad else lib.gsr_workspace_bytes_forward_only
+        while True:
+            nbytes = ws_bytes(P, W, H, cap)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            if mode == "sync" and P > 0 and _early_notify:
+                # the device publishes the instance count to pinned memory right after the binning scan; the host
+                # checks capacity while scatter / sort / compositing are still running (no GPU idle time)
+                hdr, w32, hdr_ptr, seq = ring.next_notify()
+                # the same header carries the longest bin list: as long as none has exceeded 1024 entries on this device,
+                # the (then idle, ~5 us) large-list sort launch is left out -- a surprise is reported like an overflow
+                skip_large = not st.get("big_bins", False)
+                flags = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
+                rc = lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
+                                            float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
+                                            _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
+                                            stream, hdr_ptr, seq)
+                _capi.check(rc, "gsr_forward_notify")
+                if _deferred is not None:
+                    # checked when the enclosing defer_capacity_checks() exits (several views in flight); an overflow is repaired
+                    # there, in place: same output tensors, a larger workspace in ctx.ws_box
+                    box = [ws, cap]
+                    ctx.ws_box = box
+
+                    def finish(hdr=hdr, w32=w32, seq=seq, flags=flags):
+                        while True:
+                            _wait_notify(w32, seq, cur_stream)
+                            R, overflow, need = _decode(hdr)
+                            _learn(st, R, need, P)
+                            if int(w32[3]) > 768:
+                                st["big_bins"] = True
+                            if not overflow:
+                                return
+                            if box[1] >= 0x7fffffff:
+                                raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the "
+                                                   "workspace layout can address" % R)
+                            with torch.cuda.stream(cur_stream):
+                                box[1] = _capacity_for(st, P)
+                                nb = ws_bytes(P, W, H, box[1])
+                                box[0] = torch.empty((nb,), dtype=torch.uint8, device=dev)
+                                hdr, w32, hdr_ptr2, seq = ring.next_notify()
+                                fl = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (0 if st.get("big_bins", False) else _capi.GSR_FLAG_NO_LARGE_SORT)
+                                _capi.check(lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
+                                                                   float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
+                                                                   _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(box[0]), nb, box[1], fl,
+                                                                   cur_stream.cuda_stream, hdr_ptr2, seq), "gsr_forward_notify")
+
+                    _deferred.append(finish)
+                    break
+                _wait_notify(w32, seq, cur_stream)
+                R, overflow, need = _decode(hdr)
+                _learn(st, R, need, P)
+                if int(w32[3]) > 768:
+                    st["big_bins"] = True  # sticky, with margin: from now on the large-list sort is always launched
+                if not overflow:
+                    break
+                if cap >= 0x7fffffff:
+                    raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
+                                       "layout can address" % R)
+                cap = _capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
+                continue
+            flags &= ~_capi.GSR_FLAG_NO_LARGE_SORT  # only the early-notification path can verify that shortcut
+            rc = lib.gsr_forward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
+                                 float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),
+                                 _ptr(radii), _ptr(ws), nbytes, cap, flags, stream)
+            _capi.check(rc, "gsr_forward")
+            if P == 0 or mode == "none":
+                break
+            cring = _ring(dev, "copy")
+            if mode == "deferred" and len(st["pending"]) >= cring.n - 1:
+                _drain_pending(st, block=True)  # never reuse a pinned slot that is still in flight
+            hdr, hdr_ptr, ev = cring.next()
+            _capi.check(lib.gsr_copy_header_async(_ptr(ws), hdr_ptr, stream), "gsr_copy_header_async")
+            ev.record(cur_stream)
+            if mode == "deferred":
+                st["pending"].append((ev, hdr, P))
+                break
+            ev.synchronize()
+            R, overflow, need = _decode(hdr)
+            _learn(st, R, need, P)
+            if not overflow:
+                break
+            if cap >= 0x7fffffff:
+                raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
+                                   "layout can address" % R)
+            cap = _capacity_for(st, P)  # grown by _learn; re-run the whole (cheap) forward
+    ctx.raster_settings = rs
+    ctx.cap = cap
+    ctx.family = family  # the backward must repeat the forward's per-pixel decisions: same kernel family
+    ctx.saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws)
+    return color, radii
+
+
+def _backward_impl(ctx, saved, grad_out_color, arena):
+    """One view's backward through the C-ABI.  saved: the tuple _forward_impl left in ctx.saved; arena: optional five preallocated
+    gradient tensors (means3D, colours, opacities, scales, rotations).  -> (d_m3, d_m2, d_col, d_op, d_sc, d_rot)"""
+    rs = ctx.raster_settings
+    lib = _capi.lib()
+    m3, col, opa, sca, rot, view, proj, bg, radii, ws = saved
+    cap = ctx.cap
+    box = getattr(ctx, "ws_box", None)
+    if box is not None:  # forward ran inside defer_capacity_checks(): the workspace may have been replaced by the overflow repair
+        ws, cap = box
+    dev = m3.device
+    P = m3.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    g = grad_out_color.detach().to(dtype=torch.float32).contiguous()  # H3: may arrive non-contiguous
+    with _device_guard(dev):
+        st = _dev_state(dev)
+        if _check_mode() != "none":
+            _drain_pending(st, block=(_check_mode() == "deferred"))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if arena is not None and all(a.dtype == torch.float32 and a.is_contiguous() and a.device == dev and tuple(a.shape) == (P, c)
+                                     for a, c in zip(arena, (3, 3, 1, 3, 4))):
+            d_m3, d_col, d_op, d_sc, d_rot = arena
+            d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        else:
+            # one allocation, six contiguous gradient arrays carved out of it (quaternion gradient first: it is stored as float4)
+            buf = torch.empty((P * 17,), dtype=torch.float32, device=dev)
+            d_rot = buf[:4 * P].view(P, 4)
+            d_m3 = buf[4 * P:7 * P].view(P, 3)
+            d_m2 = buf[7 * P:10 * P].view(P, 3)
+            d_col = buf[10 * P:13 * P].view(P, 3)
+            d_sc = buf[13 * P:16 * P].view(P, 3)
+            d_op = buf[16 * P:].view(P, 1)
+        if P > 0:
+            rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
+                                  float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
+                                  _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
+                                  ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | ctx.family, stream)
+            _capi.check(rc, "gsr_backward")
+    return d_m3, d_m2, d_col, d_op, d_sc, d_rot
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, grad_arena=None):
         # grad_arena (optional, internal to pts2render): five preallocated fp32 tensors [P,3],[P,3],[P,1],[P,3],[P,4] -- row slices
         # of batch-wide buffers -- that the backward writes dL/d(means3D, colours, opacities, scales, rotations) into instead of
         # fresh allocations, so that the batch's gradients arrive already concatenated (render_api._SplitRows)
-        rs = raster_settings
         ctx.grad_arena = grad_arena
-        lib = _capi.lib()
-        if not means3D.is_cuda:
-            raise RuntimeError("gps_gaussian_amd: rasteriser inputs must live on a GPU (no CPU fallback)")
-        if means3D.dim() != 2 or means3D.shape[1] != 3:
-            raise RuntimeError("means3D must have dimensions (num_points, 3)")
-        dev = means3D.device
-        P = means3D.shape[0]
-        H, W = int(rs.image_height), int(rs.image_width)
-        m3 = _prep(means3D, "means3D", (3,), dev)
-        col = _prep(colors_precomp, "colors_precomp", (3,), dev)
-        opa = _prep(opacities, "opacities", None, dev).reshape(-1)
-        sca = _prep(scales, "scales", (3,), dev)
-        rot = _prep(rotations, "rotations", (4,), dev)
-        if not (col.shape[0] == opa.shape[0] == sca.shape[0] == rot.shape[0] == P):
-            raise RuntimeError("all per-Gaussian inputs must have num_points rows")
-        view = _cam(rs.viewmatrix, 16, dev)
-        proj = _cam(rs.projmatrix, 16, dev)
-        bg = _cam(rs.bg, 3, dev)
-        family = _composite_flag()
-        flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | family
-        mode = _check_mode()
-        st = _dev_state(dev)
-        if mode != "none" and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("gps_gaussian_amd: the capacity check reads a header back on the host and cannot run under graph capture; "
-                               "warm up eagerly, then capture with GPSGS_CHECK=none")
-        with _device_guard(dev):
-            if mode != "none":
-                _drain_pending(st)
-            cur_stream = torch.cuda.current_stream(dev)
-            stream = cur_stream.cuda_stream
-            ring = _ring(dev)
-            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-            radii = torch.empty((P,), dtype=torch.int32, device=dev)
-            cap = _capacity_for(st, P)
-            # inference (no input needs a gradient): skip the backward tail of the workspace (52 B per instance slot)
-            ws_bytes = lib.gsr_workspace_bytes if any(ctx.needs_input_grad) else lib.gsr_workspace_bytes_forward_only
-            while True:
-                nbytes = ws_bytes(P, W, H, cap)
-                ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-                if mode == "sync" and P > 0 and _early_notify:
-                    # the device publishes the instance count to pinned memory right after the binning scan; the host
-                    # checks capacity while scatter / sort / compositing are still running (no GPU idle time)
-                    hdr, w32, hdr_ptr, seq = ring.next_notify()
-                    # the same header carries the longest bin list: as long as none has exceeded 1024 entries on this device,
-                    # the (then idle, ~5 us) large-list sort launch is left out -- a surprise is reported like an overflow
-                    skip_large = not st.get("big_bins", False)
-                    flags = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
-                    rc = lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
-                                                float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
-                                                _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
-                                                stream, hdr_ptr, seq)
-                    _capi.check(rc, "gsr_forward_notify")
-                    if _deferred is not None:
-                        # checked when the enclosing defer_capacity_checks() exits (several views in flight); an overflow is repaired
-                        # there, in place: same output tensors, a larger workspace in ctx.ws_box
-                        box = [ws, cap]
-                        ctx.ws_box = box
-
-                        def finish(hdr=hdr, w32=w32, seq=seq, flags=flags):
-                            while True:
-                                _wait_notify(w32, seq, cur_stream)
-                                R, overflow, need = _decode(hdr)
-                                _learn(st, R, need, P)
-                                if int(w32[3]) > 768:
-                                    st["big_bins"] = True
-                                if not overflow:
-                                    return
-                                if box[1] >= 0x7fffffff:
-                                    raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the "
-                                                       "workspace layout can address" % R)
-                                with torch.cuda.stream(cur_stream):
-                                    box[1] = _capacity_for(st, P)
-                                    nb = ws_bytes(P, W, H, box[1])
-                                    box[0] = torch.empty((nb,), dtype=torch.uint8, device=dev)
-                                    hdr, w32, hdr_ptr2, seq = ring.next_notify()
-                                    fl = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (0 if st.get("big_bins", False) else _capi.GSR_FLAG_NO_LARGE_SORT)
-                                    _capi.check(lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
-                                                                       float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
-                                                                       _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(box[0]), nb, box[1], fl,
-                                                                       cur_stream.cuda_stream, hdr_ptr2, seq), "gsr_forward_notify")
-
-                        _deferred.append(finish)
-                        break
-                    _wait_notify(w32, seq, cur_stream)
-                    R, overflow, need = _decode(hdr)
-                    _learn(st, R, need, P)
-                    if int(w32[3]) > 768:
-                        st["big_bins"] = True  # sticky, with margin: from now on the large-list sort is always launched
-                    if not overflow:
-                        break
-                    if cap >= 0x7fffffff:
-                        raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
-                                           "layout can address" % R)
-                    cap = _capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
-                    continue
-                flags &= ~_capi.GSR_FLAG_NO_LARGE_SORT  # only the early-notification path can verify that shortcut
-                rc = lib.gsr_forward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
-                                     float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),
-                                     _ptr(radii), _ptr(ws), nbytes, cap, flags, stream)
-                _capi.check(rc, "gsr_forward")
-                if P == 0 or mode == "none":
-                    break
-                cring = _ring(dev, "copy")
-                if mode == "deferred" and len(st["pending"]) >= cring.n - 1:
-                    _drain_pending(st, block=True)  # never reuse a pinned slot that is still in flight
-                hdr, hdr_ptr, ev = cring.next()
-                _capi.check(lib.gsr_copy_header_async(_ptr(ws), hdr_ptr, stream), "gsr_copy_header_async")
-                ev.record(cur_stream)
-                if mode == "deferred":
-                    st["pending"].append((ev, hdr, P))
-                    break
-                ev.synchronize()
-                R, overflow, need = _decode(hdr)
-                _learn(st, R, need, P)
-                if not overflow:
-                    break
-                if cap >= 0x7fffffff:
-                    raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
-                                       "layout can address" % R)
-                cap = _capacity_for(st, P)  # grown by _learn; re-run the whole (cheap) forward
-        ctx.raster_settings = rs
-        ctx.cap = cap
-        ctx.family = family  # the backward must repeat the forward's per-pixel decisions: same kernel family
-        ctx.save_for_backward(m3, col, opa, sca, rot, view, proj, bg, radii, ws)
+        color, radii = _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, any(ctx.needs_input_grad))
+        ctx.save_for_backward(*ctx.saved)
+        ctx.saved = None
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # otherwise autograd fills a zero int32 [P] "gradient" for radii on every backward
         return color, radii
@@ -399,42 +465,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         if grad_out_color is None:  # the image did not take part in the loss
             return (None,) * 10
-        rs = ctx.raster_settings
-        lib = _capi.lib()
-        m3, col, opa, sca, rot, view, proj, bg, radii, ws = ctx.saved_tensors
-        cap = ctx.cap
-        box = getattr(ctx, "ws_box", None)
-        if box is not None:  # forward ran inside defer_capacity_checks(): the workspace may have been replaced by the overflow repair
-            ws, cap = box
-        dev = m3.device
-        P = m3.shape[0]
-        H, W = int(rs.image_height), int(rs.image_width)
-        g = grad_out_color.detach().to(dtype=torch.float32).contiguous()  # H3: may arrive non-contiguous
-        with _device_guard(dev):
-            st = _dev_state(dev)
-            if _check_mode() != "none":
-                _drain_pending(st, block=(_check_mode() == "deferred"))
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            arena = ctx.grad_arena
-            if arena is not None and all(a.dtype == torch.float32 and a.is_contiguous() and a.device == dev and tuple(a.shape) == (P, c)
-                                         for a, c in zip(arena, (3, 3, 1, 3, 4))):
-                d_m3, d_col, d_op, d_sc, d_rot = arena
-                d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)
-            else:
-                # one allocation, six contiguous gradient arrays carved out of it (quaternion gradient first: it is stored as float4)
-                buf = torch.empty((P * 17,), dtype=torch.float32, device=dev)
-                d_rot = buf[:4 * P].view(P, 4)
-                d_m3 = buf[4 * P:7 * P].view(P, 3)
-                d_m2 = buf[7 * P:10 * P].view(P, 3)
-                d_col = buf[10 * P:13 * P].view(P, 3)
-                d_sc = buf[13 * P:16 * P].view(P, 3)
-                d_op = buf[16 * P:].view(P, 1)
-            if P > 0:
-                rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
-                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
-                                      _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
-                                      ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | ctx.family, stream)
-                _capi.check(rc, "gsr_backward")
+        d_m3, d_m2, d_col, d_op, d_sc, d_rot = _backward_impl(ctx, ctx.saved_tensors, grad_out_color, ctx.grad_arena)
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
         return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None, None
 

@@ -24,6 +24,25 @@ def _streams(dev, n):
     return pool[:n]
 
 
+_bg_cache = {}
+
+
+def _bg_tensor(bg_color, dev):
+    """The background colour on the device.  torch.tensor(list, device=cuda) -- what the reference does per render() call,
+    gaussian_renderer/__init__.py:23 -- is a SYNCHRONOUS copy from pageable memory: it blocks the host until the stream has drained
+    (measured 0.35 ms per stage-2 iteration, and it stops the host from running ahead of the GPU).  The handful of distinct colours a
+    run uses are kept on the device instead."""
+    if isinstance(bg_color, torch.Tensor):
+        return bg_color.to(device=dev, dtype=torch.float32)
+    key = (tuple(float(c) for c in bg_color), dev.index)
+    t = _bg_cache.get(key)
+    if t is None:
+        if len(_bg_cache) > 64:
+            _bg_cache.clear()
+        t = _bg_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
+    return t
+
+
 def _scalar(x):
     return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
 
@@ -58,11 +77,75 @@ class _SplitRows(torch.autograd.Function):
         return torch.cat(parts, dim=0), None, None
 
 
+class _Holder:
+    """Attribute holder handed to rasterizer._forward_impl / _backward_impl in place of an autograd ctx (one per view of a batch)."""
+    pass
+
+
+class _RenderBatch(torch.autograd.Function):
+    """All samples of a pts2render batch as ONE autograd node: B raster forwards enqueued back to back on B HIP streams (the views
+    are independent and one view leaves the chip under-occupied: DESIGN.md section 4), their exact capacity checks collected and run
+    once all are in flight, the images written straight into one [B,3,H,W] tensor; the backward does the same with the B raster
+    backwards, each writing its rows of five batch-wide gradient buffers.  Replaces, per iteration, 5 split nodes + B rasteriser
+    nodes + one concatenation (and their Python), which is what kept the per-sample form host-bound (tools/stage2_ab.py).
+    Numerically it IS the per-sample path: the same C-ABI calls on the same rows (tests/test_gpu_pack.py compares the bits)."""
+
+    @staticmethod
+    def forward(ctx, xyz, rgb, rot, scale, opacity, offs, settings):
+        # xyz .. opacity: packed [N, C] fp32 (pack.pack_views); offs: B + 1 row offsets (host ints); settings: B GaussianRasterizationSettings
+        bs = len(settings)
+        dev = xyz.device
+        H, W = int(settings[0].image_height), int(settings[0].image_width)
+        out = torch.empty((bs, 3, H, W), dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side = _streams(dev, bs) if bs > 1 else [cur]
+        needs = any(ctx.needs_input_grad[:5])
+        views = []
+        with _RZ.defer_capacity_checks():
+            for i in range(bs):
+                a, b = offs[i], offs[i + 1]
+                h = _Holder()
+                if side[i] is not cur:
+                    side[i].wait_stream(cur)
+                with torch.cuda.stream(side[i]):
+                    _RZ._forward_impl(h, xyz[a:b], rgb[a:b], opacity[a:b], scale[a:b], rot[a:b], settings[i], needs, out_color=out[i])
+                views.append(h)
+        for i in range(bs):
+            if side[i] is not cur:
+                cur.wait_stream(side[i])
+        ctx.views, ctx.offs, ctx.side = views, offs, side
+        ctx.shapes = tuple(tuple(t.shape) for t in (xyz, rgb, rot, scale, opacity))
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if gout is None:
+            return (None,) * 7
+        views, offs, side = ctx.views, ctx.offs, ctx.side
+        dev = gout.device
+        g = gout.detach().to(dtype=torch.float32).contiguous()
+        # one gradient buffer per packed tensor; every view's backward writes its own rows, rows behind offs[-1] (the unused tail of
+        # the packed capacity) are never read by the pack backward
+        d_xyz, d_rgb, d_rot, d_scale, d_op = (torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes)
+        cur = torch.cuda.current_stream(dev)
+        for i, h in enumerate(views):
+            a, b = offs[i], offs[i + 1]
+            if side[i] is not cur:
+                side[i].wait_stream(cur)
+            with torch.cuda.stream(side[i]):  # (a workspace replaced by the overflow repair is picked up from h.ws_box in there)
+                _RZ._backward_impl(h, h.saved, g[i], (d_xyz[a:b], d_rgb[a:b], d_op[a:b], d_scale[a:b], d_rot[a:b]))
+        for i in range(len(views)):
+            if side[i] is not cur:
+                cur.wait_stream(side[i])
+        return d_xyz, d_rgb, d_rot, d_scale, d_op, None, None
+
+
 def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color, grad_arena=None):
     """Render one novel view.  Same arguments and return value as the reference's render(): returns image [3,H,W].
     (grad_arena: internal, see pts2render.)"""
     nv = data['novel_view']
-    bg = torch.tensor(bg_color, dtype=torch.float32, device=pts_xyz.device)
+    bg = _bg_tensor(bg_color, pts_xyz.device)
     screenspace_points = torch.zeros_like(pts_xyz, dtype=torch.float32, requires_grad=True, device=pts_xyz.device) + 0
     try:
         screenspace_points.retain_grad()
@@ -79,21 +162,55 @@ def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color, gr
     return rendered_image
 
 
+def _settings(nv, idx, bg, view=None, proj=None):
+    return GaussianRasterizationSettings(
+        image_height=int(nv['height'][idx]), image_width=int(nv['width'][idx]),
+        tanfovx=math.tan(_scalar(nv['FovX'][idx]) * 0.5), tanfovy=math.tan(_scalar(nv['FovY'][idx]) * 0.5),
+        bg=bg, scale_modifier=1.0, viewmatrix=(nv['world_view_transform'] if view is None else view)[idx],
+        projmatrix=(nv['full_proj_transform'] if proj is None else proj)[idx],
+        sh_degree=3, campos=nv['camera_center'][idx], prefiltered=False, debug=False)
+
+
+def _to_device_once(t, dev):
+    """[B,4,4] camera matrices of the whole batch in ONE copy (H1: in training they arrive as pinned CPU tensors; per-sample slices
+    would each cost their own small H2D copy)."""
+    if t.device != dev or t.dtype != torch.float32 or t.requires_grad or not t.is_contiguous():
+        t = t.detach().to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+    return t
+
+
 def pts2render(data, bg_color):
     """Same contract as the reference's pts2render(): writes data['novel_view']['img_pred'] = [B,3,H,W].
 
     The flatten / mask-gather / concat / rgb-affine of lib/GaussianRender.py:15-34 runs as one fused op for the whole batch
     (pack.py: 3 launches, no sync) instead of 10 boolean-index gathers + syncs per sample; the only host read is the B+1
-    row offsets that give every sample's tensors their exact shape."""
+    row offsets that give every sample's tensors their exact shape.  The B renders then run as ONE autograd node with the samples
+    on B HIP streams (_RenderBatch).  GPSGS_PTS2RENDER=loop restores the literal per-sample loop of render() calls (also taken
+    under graph capture and when the samples differ in image size)."""
     from .pack import pack_views
 
     bs = data['lmain']['img'].shape[0]
     xyz, rgb, rot, scale, opacity, offsets = pack_views(data)
-    offs = offsets.tolist()
+    nv = data['novel_view']
+    dev = xyz.device
+    sizes_hw = {(int(nv['height'][i]), int(nv['width'][i])) for i in range(bs)}
+    if os.environ.get("GPSGS_PTS2RENDER", "batch") != "loop" and len(sizes_hw) == 1 and not torch.cuda.is_current_stream_capturing():
+        # everything that does not need the row offsets is prepared while the pack kernels run; the offsets' read-back is the one sync
+        bg = _bg_tensor(bg_color, dev)
+        view, proj = _to_device_once(nv['world_view_transform'], dev), _to_device_once(nv['full_proj_transform'], dev)
+        settings = [_settings(nv, i, bg, view, proj) for i in range(bs)]
+        nv['img_pred'] = _RenderBatch.apply(xyz, rgb, rot, scale, opacity, offsets.tolist(), settings)
+        return data
+    return _pts2render_loop(data, bg_color, (xyz, rgb, rot, scale, opacity), offsets.tolist())
+
+
+def _pts2render_loop(data, bg_color, packed, offs):
+    """The per-sample form: one render() (one rasteriser autograd node) per sample, on the current stream."""
+    bs = data['lmain']['img'].shape[0]
+    xyz, rgb, rot, scale, opacity = packed
     # ONE split per packed tensor (its backward is one concatenation of the per-sample gradients); B Python slices would make
     # autograd zero-fill and add a full-size gradient per sample and tensor (measured: 0.6 ms of a 4.1 ms stage-2 iteration)
     sizes = [offs[i + 1] - offs[i] for i in range(bs)] + [xyz.shape[0] - offs[bs]]
-    packed = (xyz, rgb, rot, scale, opacity)
     if any(t.requires_grad for t in packed):
         # gradient arenas: one buffer per packed tensor; every sample's rasteriser backward writes its rows in place and the
         # split's backward hands the whole buffer on (no per-sample allocation, no concatenation).  Rows behind offs[bs] are
@@ -106,12 +223,8 @@ def pts2render(data, bg_color):
     out = []
     dev = xyz.device
     cur = torch.cuda.current_stream(dev)
-    # One view's kernels leave the chip under-occupied (~5 one-wave compositing work items per SIMD at 1024^2 / 600k Gaussians), and the
-    # samples of a batch are independent: with GPSGS_PTS2RENDER_STREAMS=1 each is enqueued on its own HIP stream so that they render
-    # concurrently (the reference loops over them on one stream, lib/GaussianRender.py:9); their capacity checks are collected and run
-    # after all of them are in flight, and autograd runs every sample's backward on the stream of its forward.  Off by default: through
-    # PyTorch's autograd the batch loop is host-bound (tools/stage2_ab.py: 2.73 ms vs 2.79 ms per iteration of 4 pairs), so the overlap
-    # that the C-ABI sessions get (bench.py --inflight: +27 %) does not materialise here.
+    # GPSGS_PTS2RENDER_STREAMS=1: each sample on its own HIP stream also in this form (measured no gain: through B autograd nodes the
+    # batch loop is host-bound, tools/stage2_ab.py -- the reason _RenderBatch exists)
     concurrent = bs > 1 and not torch.cuda.is_current_stream_capturing() and os.environ.get("GPSGS_PTS2RENDER_STREAMS", "0") == "1"
     side = _streams(dev, bs) if concurrent else [cur] * bs
     with _RZ.defer_capacity_checks():

@@ -78,11 +78,13 @@ def test_pack_backward_matches_torch_mask_gather():
             assert torch.equal(got[v][k], data[v][k].grad), (v, k)
 
 
-@pytest.mark.parametrize("streams", ["0", "1"], ids=["one-stream", "stream-per-sample"])
-def test_fused_pts2render_equals_unfused_and_oracle_path(streams, monkeypatch):
-    """pts2render (fused pack) and the literal per-sample version give the same image bits and the same map gradients -- also when the
-    samples of the batch are rendered concurrently on their own streams (GPSGS_PTS2RENDER_STREAMS=1)."""
+@pytest.mark.parametrize("mode,streams", [("batch", "0"), ("loop", "0"), ("loop", "1")], ids=["one-node-stream-per-sample", "loop-one-stream", "loop-stream-per-sample"])
+def test_fused_pts2render_equals_unfused_and_oracle_path(mode, streams, monkeypatch):
+    """pts2render (fused pack + the whole batch as ONE autograd node with the samples on their own streams: the default) and the literal
+    per-sample version give the same image bits and the same map gradients -- also in the per-sample loop form (GPSGS_PTS2RENDER=loop),
+    with the samples on one stream or on their own streams (GPSGS_PTS2RENDER_STREAMS=1)."""
     import torch
+    monkeypatch.setenv("GPSGS_PTS2RENDER", mode)
     monkeypatch.setenv("GPSGS_PTS2RENDER_STREAMS", streams)
     from conftest import simple_scene
     from gps_gaussian_amd import render_api

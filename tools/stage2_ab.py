@@ -26,11 +26,40 @@ def step():
             data[v][k].grad = None
     img = render_api.pts2render(data, [0, 0, 0])["novel_view"]["img_pred"]
     L.stage2_photometric_loss(img, gt).backward()
-for fam in ("valu", "tiles"):
-    for streams in ("0", "1"):
-        os.environ["GPSGS_COMPOSITE"] = fam; os.environ["GPSGS_PTS2RENDER_STREAMS"] = streams
+for fam in ("tiles",):
+    for mode, streams in (("batch", "0"), ("loop", "0"), ("loop", "1")):
+        os.environ["GPSGS_COMPOSITE"] = fam; os.environ["GPSGS_PTS2RENDER"] = mode; os.environ["GPSGS_PTS2RENDER_STREAMS"] = streams
         for _ in range(5): step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20): step()
         torch.cuda.synchronize()
-        print(json.dumps({"family": fam, "samples_concurrent": streams == "1", "ms_per_iter": round((time.perf_counter() - t0) / 20 * 1e3, 3)}))
+        print(json.dumps({"family": fam, "pts2render": mode, "samples_concurrent": mode == "batch" or streams == "1",
+                          "ms_per_iter": round((time.perf_counter() - t0) / 20 * 1e3, 3)}))
+# where the time of the default form goes: the same loop under the profiler would perturb it; time the parts instead
+os.environ["GPSGS_PTS2RENDER"] = "batch"
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / n * 1e3, 3)
+def fwd_only():
+    with torch.no_grad():
+        render_api.pts2render(data, [0, 0, 0])
+img0 = render_api.pts2render(data, [0, 0, 0])["novel_view"]["img_pred"].detach().requires_grad_(True)
+def loss_only():
+    img0.grad = None
+    L.stage2_photometric_loss(img0, gt).backward()
+print(json.dumps({"pts2render_forward_only_ms": timeit(fwd_only), "loss_fwd_bwd_ms": timeit(loss_only)}))
+if os.environ.get("STAGE2_CPROFILE"):
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(20): step()
+    torch.cuda.synchronize()
+    pr.disable()
+    sio = io.StringIO()
+    pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(45)
+    print(sio.getvalue()[:9000])
