@@ -160,7 +160,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     {
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
         if (flags & GSR_FLAG_COMPOSITE_TILES)
-            gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+            gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, training, s);
         else
             gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
     }

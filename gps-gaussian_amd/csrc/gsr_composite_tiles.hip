@@ -24,7 +24,9 @@ struct TileFwdState {
     lanemask_t active;
 };
 
-template <int S>
+// KEEP: the per-pixel state the backward starts from (final T, index of the last contributor) is tracked and written; an inference
+// workspace (no backward tail) takes the instantiation without it: one select per pair and 8 bytes per pixel less
+template <int S, bool KEEP>
 __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wCol, int cnt) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -51,12 +53,13 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
                 st.C1 += c.z * w;
                 st.C2 += c.w * w;
                 st.T = use ? test_T : st.T;
-                st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
+                if (KEEP) st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
             }
         }
     }
 }
 
+template <bool KEEP>
 __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
@@ -101,19 +104,23 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
         const int cnt = (int)min((uint32_t)WAVE, r1 - base);
         {
             const f32x16 d0 = pow_tile_bf16(opA.a[0], opB.b[0]), d1 = pow_tile_bf16(opA.a[0], opB.b[1]);
-            tiles_fwd_half<0>(st, d0, d1, sCol, cnt);
+            tiles_fwd_half<0, KEEP>(st, d0, d1, sCol, cnt);
         }
         if (cnt > 32 && st.active != 0ull) {
             const f32x16 d0 = pow_tile_bf16(opA.a[1], opB.b[0]), d1 = pow_tile_bf16(opA.a[1], opB.b[1]);
-            tiles_fwd_half<1>(st, d0, d1, sCol, cnt);
+            tiles_fwd_half<1, KEEP>(st, d0, d1, sCol, cnt);
         }
-        last = st.last_rnd ? (base - r0) + st.last_rnd : last;
-        st.last_rnd = 0;
+        if (KEEP) {
+            last = st.last_rnd ? (base - r0) + st.last_rnd : last;
+            st.last_rnd = 0;
+        }
     }
     if (g.inside) {
         const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
-        final_T[q] = st.T;
-        n_contrib[q] = last;
+        if (KEEP) {
+            final_T[q] = st.T;
+            n_contrib[q] = last;
+        }
         out_color[q] = st.C0 + st.T * bg[0];
         out_color[npix + q] = st.C1 + st.T * bg[1];
         out_color[2 * npix + q] = st.C2 + st.T * bg[2];
@@ -430,11 +437,15 @@ __global__ __launch_bounds__(64) void k_selftest_tiles(float *__restrict__ out) 
 
 void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
-                                    const GsrHeader *hdr, hipStream_t s) {
+                                    const GsrHeader *hdr, bool keep_state, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_fwd_tiles, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
-                       out_color, final_T, n_contrib, hdr);
+    if (keep_state)
+        hipLaunchKernelGGL(k_composite_fwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list,
+                           bg, out_color, final_T, n_contrib, hdr);
+    else
+        hipLaunchKernelGGL(k_composite_fwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list,
+                           bg, out_color, final_T, n_contrib, hdr);
 }
 
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,

@@ -82,12 +82,14 @@ typedef struct GsrHeader {      /* first bytes of the workspace, device memory *
     uint32_t overflow;          /* 1 if R (or, with a backward tail, num_slots) > instance_capacity */
     uint32_t max_tile_count;    /* longest per-bin list (one 8x8-pixel bin = one wave64 work item) */
     uint32_t num_busy_wgs;      /* bins with a non-empty list; they are scheduled first */
-    uint32_t num_slots;         /* training workspaces only: bin-rect cells of all Gaussians (inst_pos slots); also <= capacity */
+    uint32_t num_slots;         /* training workspaces only: bin-rect cells of all Gaussians (one gradient-record slot each); also <= capacity */
     uint32_t reserved[10];
 } GsrHeader;
 
 size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity);              /* forward + backward */
-size_t gsr_workspace_bytes_forward_only(int P, int width, int height, int64_t instance_capacity); /* inference: no backward tail */
+size_t gsr_workspace_bytes_forward_only(int P, int width, int height, int64_t instance_capacity); /* inference: no backward tail; a forward on
+                                                                                                     such a workspace also skips the per-pixel state
+                                                                                                     only a backward reads (final T, last contributor) */
 
 /* Forward.  Inputs fp32, contiguous: means3D[P,3], colors[P,3], opacities[P], scales[P,3], rotations[P,4] (w,x,y,z;
  * NOT re-normalised), viewmatrix[16], projmatrix[16] (flat column-major = the transposed tensors the reference
@@ -142,7 +144,8 @@ int gsr_timing_read(float *ms_sum_host, int *launches_host);
 /* Debug/parity helper: copies selected intermediate arrays out of the workspace into caller DEVICE buffers (any may
  * be NULL): depth[P], xy[P,2], conic_opacity[P,4], rect[P,4] (int32 bx0,by0,bx1,by1: the 8x8-pixel BIN rect the Gaussian
  * is listed in), tile_ranges[NB,2] (int64 list range per bin; NB = (ceil(W/8) rounded up to 4) * ceil(H/8)),
- * point_list[num_rendered] (uint32, sorted per bin), final_T[H,W], n_contrib[H,W]. */
+ * point_list[num_rendered] (uint32, sorted per bin), final_T[H,W], n_contrib[H,W] (the last two are only produced by a
+ * forward on a workspace with the backward tail). */
 int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, float *depth,
                      float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges, uint32_t *point_list,
                      float *final_T, uint32_t *n_contrib, void *stream);

@@ -31,7 +31,7 @@ while i < len(lines):
     if m and ("k_" in m.group(1)):
         name = m.group(1)
         j = i
-        while j < len(lines) and "s_endpgm" not in lines[j]: j += 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"): j += 1  # (a kernel with early exits has several s_endpgm)
         body = lines[i:j + 1]
         if want in name:
             ops = [re.match(r"\s+([a-z_0-9]+)", l).group(1) for l in body if re.match(r"\s+[vsd]_|\s+(global|buffer|flat|ds)_", l)]
