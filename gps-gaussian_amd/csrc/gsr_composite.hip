@@ -15,10 +15,12 @@
 //     are taken from the work-ordered list in an XCD-aware order (xcd_list_pos) so that neighbouring bins share an L2;
 //   * backward: the 9 per-(pixel, splat) gradient terms are summed across the wave with a butterfly reduce-scatter
 //     (v_permlane32/16_swap + DPP, 22 instructions instead of 54, no LDS traffic), parked per staged splat in LDS by
-//     12 lanes and flushed once per round as 64-byte (48 used) per-INSTANCE records with plain coalesced stores.  There is no
-//     global atomic in the backward at all (upstream issues 10 per (pixel, splat); float atomics run at only
-//     20-30 Mops/ms on MI355X): k_preprocess_bwd gathers each Gaussian's few instance records in a fixed order, so
+//     12 lanes and flushed once per round as one 32-byte record + dL/dopacity + flag per INSTANCE, at the instance's Gaussian-major
+//     slot (gsr_common.h).  There is no global atomic in the backward at all (upstream issues 10 per (pixel, splat); float
+//     atomics run at only 20-30 Mops/ms on MI355X): k_preprocess_bwd streams each Gaussian's slots in a fixed order, so
 //     gradients are also bit-reproducible.
+// This file is the VALU-only kernel family (GPSGS_COMPOSITE=valu); the default family takes the exponents from matrix-core tiles
+// (gsr_composite_tiles.hip).
 #include "gsr_composite_common.h"
 
 namespace {

@@ -122,7 +122,7 @@ def _drain_pending(st, block=False):
 
 
 def _decode(hdr):
-    """hdr: int64[4] view of the first 32 header bytes -> (R, overflow, capacity needed = max(R, inst_pos slots))."""
+    """hdr: int64[4] view of the first 32 header bytes -> (R, overflow, capacity needed = max(R, gradient-record slots))."""
     R = int(hdr[0])
     overflow = int(hdr[1]) & 0xffffffff
     slots = (int(hdr[2]) >> 32) & 0xffffffff

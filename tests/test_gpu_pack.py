@@ -115,3 +115,43 @@ def test_fused_pts2render_equals_unfused_and_oracle_path(mode, streams, monkeypa
     for v in g_f:
         for k in g_f[v]:
             assert torch.equal(g_f[v][k], g_u[v][k]), (v, k)
+
+
+def test_batch_with_a_sample_without_valid_points(monkeypatch):
+    """A sample whose validity masks are all false has P = 0: upstream returns its zero-initialised image (NOT the background) and
+    no gradient reaches its maps; the other sample of the batch is unaffected.  Both forms of pts2render agree with the literal mirror."""
+    import torch
+    from conftest import simple_scene
+    from gps_gaussian_amd import render_api
+    dev = torch.device("cuda:0")
+    B, side = 2, 64
+    cam = simple_scene(side, side, 48.0)
+    res = {}
+    for mode, fn in (("batch", render_api.pts2render), ("loop", render_api.pts2render), ("literal", render_api.pts2render_unfused)):
+        monkeypatch.setenv("GPSGS_PTS2RENDER", "loop" if mode == "loop" else "batch")
+        _, data = _data_from_golden(dev, requires_grad=True)
+        for v in ("lmain", "rmain"):
+            data[v]["xyz"] = (data[v]["xyz"] * 0.1 + torch.tensor([0.0, 0.0, 2.0], device=dev))
+            data[v]["scale_maps_in"] = data[v]["scale_maps"]
+            data[v]["scale_maps"] = data[v]["scale_maps"] * 5
+            data[v]["pts_valid"] = data[v]["pts_valid"].clone()
+            data[v]["pts_valid"][0] = False      # sample 0: nothing to draw
+        data["novel_view"] = dict(
+            FovX=torch.tensor([2 * np.arctan(cam["tanfovx"])] * B), FovY=torch.tensor([2 * np.arctan(cam["tanfovy"])] * B),
+            width=torch.tensor([side] * B), height=torch.tensor([side] * B),
+            world_view_transform=torch.from_numpy(cam["view"])[None].repeat(B, 1, 1),
+            full_proj_transform=torch.from_numpy(cam["proj"])[None].repeat(B, 1, 1), camera_center=torch.zeros(B, 3))
+        img = fn(data, [0.2, 0.3, 0.4])["novel_view"]["img_pred"]
+        torch.manual_seed(1)
+        (img * torch.randn_like(img)).sum().backward()
+        res[mode] = (img.detach(), {v: data[v]["opacity_maps"].grad.clone() for v in ("lmain", "rmain")})
+    img_b, g_b = res["batch"]
+    assert float(img_b[0].abs().max()) == 0.0          # zero image, not the background colour
+    assert float(img_b[1].abs().max()) > 0.0
+    for v in g_b:
+        assert float(g_b[v][0].abs().max()) == 0.0     # no gradient into the maps of the empty sample
+        assert float(g_b[v][1].abs().max()) > 0.0
+    for mode in ("loop", "literal"):
+        assert torch.equal(res[mode][0], img_b), mode
+        for v in g_b:
+            assert torch.equal(res[mode][1][v], g_b[v]), (mode, v)

@@ -267,7 +267,7 @@ def test_capacity_overflow_is_detected_and_repaired(monkeypatch, early):
 
 
 def test_capacity_between_instances_and_slots_is_an_overflow(monkeypatch):
-    """The backward's inst_pos table needs one slot per bin-rect CELL, which exceeds the number of listed instances once
+    """The backward's gradient records need one slot per bin-rect CELL, which exceeds the number of listed instances once
     exact culling drops cells.  A capacity of R + 8 must therefore be reported as an overflow for a training workspace
     (found by the torch-free C++ host test) and be repaired transparently."""
     import torch
@@ -643,7 +643,7 @@ def test_raster_session_matches_the_autograd_module_bit_for_bit(monkeypatch):
 def test_unchecked_overflow_gives_a_blank_image_and_zero_gradients(monkeypatch):
     """GPSGS_CHECK=none (the HIP-graph mode) never looks at the header.  If a view then needs more instances than the workspace holds,
     nothing can be rendered from the truncated lists: the forward must leave a defined blank image (not uninitialised memory) and the
-    backward exact zeros (k_preprocess_bwd used to gather through never-written inst_pos / inst_grad entries)."""
+    backward exact zeros (k_preprocess_bwd used to read never-written gradient-record slots)."""
     import torch
     from gps_gaussian_amd import rasterizer as RZ
     from gps_gaussian_amd import synthetic as S
