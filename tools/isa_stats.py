@@ -19,12 +19,18 @@ out = "/tmp/isa_%s.s" % unit
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *flags, *extra, "-S", "--cuda-device-only", "-o", out, path], check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 meta = {}
-cur = None
-for l in lines:
-    m = re.match(r"\s+\.name:\s+(\S+)", l)
-    if m: cur = m.group(1); meta.setdefault(cur, {})
-    m = re.match(r"\s+\.(vgpr_count|sgpr_count|vgpr_spill_count|group_segment_fixed_size):\s+(\d+)", l)
-    if m and cur: meta[cur][m.group(1)] = int(m.group(2))
+blk = {}
+for l in lines:  # amdhsa.kernels metadata: one YAML list item per kernel ("  - .agpr_count: ..."), .name somewhere inside it
+    if re.match(r"\s+- \.", l):
+        if "name" in blk: meta[blk["name"]] = blk
+        blk = {}
+    m = re.match(r"\s+(?:- )?\.name:\s+(\S+)", l)
+    if m and "name" not in blk and not l.strip().startswith("- .name") or (m and l.strip().startswith(".name:") and "name" not in blk):
+        blk["name"] = m.group(1)
+    m = re.match(r"\s+(?:- )?\.(vgpr_count|sgpr_count|vgpr_spill_count|group_segment_fixed_size):\s+(\d+)", l)
+    if m: blk[m.group(1)] = int(m.group(2))
+if "name" in blk: meta[blk["name"]] = blk
+for v in meta.values(): v.pop("name", None)
 i = 0
 while i < len(lines):
     m = re.match(r"^(_Z\w+):", lines[i])
