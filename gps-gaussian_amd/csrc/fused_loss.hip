@@ -4,9 +4,11 @@
 //     0.8 * l1_loss(pred, gt) + 0.2 * (1 - ssim(pred, gt))          on [B,3,2048,2048]
 // with /root/reference/lib/loss.py:36-83: ssim() = five depthwise 11x11 convolutions (zero padding, Gaussian window
 // sigma 1.5) + ~15 elementwise kernels, and autograd replays all of it backwards.  Here:
-//   k_loss_fwd   one 32x32 output tile per workgroup: the 42x42 halo of pred and gt is staged in LDS ONCE, the window is
-//                applied separably (11 + 11 taps instead of 121; every thread slides it over 4 adjacent outputs, so 14 LDS
-//                values feed 44 taps) to the five moments x1, x2, x1^2, x2^2, x1 x2, the SSIM
+//   k_loss_fwd   one 32x32 output tile per workgroup: the window is applied separably (11 + 11 taps instead of 121) to the five
+//                moments x1, x2, x1^2, x2^2, x1 x2.  Horizontal pass: every thread reads 16 consecutive inputs of one halo row
+//                STRAIGHT FROM GLOBAL MEMORY (four dword-aligned 16-byte loads; the 42x42 halo is L2 / L1 resident, a staging
+//                tile in LDS cost a pass, a barrier and 15 KB that capped the CU at 3 workgroups) and slides the window over 4
+//                adjacent outputs (14 values feed 44 taps); only the row-filtered moments go through LDS.  Vertical pass: the SSIM
 //                map value and the three partial-derivative maps the backward needs are formed in registers, |x1 - x2|
 //                is added, and per-workgroup partial sums are written (deterministic two-level reduction, no atomics);
 //   k_loss_reduce  sums the partials in double -> {mean L1, mean SSIM};
@@ -19,7 +21,6 @@
 namespace {
 
 constexpr int TS = 32, R = 5, HS = TS + 2 * R;  // tile side, window radius, halo side (42)
-constexpr int TST = HS + 2;                     // row stride of the staged tiles: 44 floats, so 16-byte row reads stay aligned
 constexpr int XG = TS / 4;                      // every thread produces 4 ADJACENT outputs per pass from a sliding window:
                                                 // 14 LDS values feed 4 x 11 taps (3.4x fewer LDS reads than one output per thread)
 
@@ -37,36 +38,45 @@ __device__ __forceinline__ float block_sum_256(float v, float *red /*[4]*/) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// 16 consecutive floats of a staged row (the sliding window uses the first 14)
-__device__ __forceinline__ void load_row16(const float *row, float (&v)[16]) {
+struct __attribute__((aligned(4))) F4u {  // 16 bytes at dword alignment (gfx950 global_load_dwordx4 needs no more)
+    float x, y, z, w;
+};
+// 16 consecutive floats img[gy][gx0 .. gx0 + 15] with the zero padding of conv2d(padding = 5) (the sliding window uses the first 14).
+// fast: the whole span lies inside the row (decided per workgroup) -> four 16-byte loads; otherwise element by element.
+__device__ __forceinline__ void load_row16(const float *__restrict__ img, int H, int W, int gy, int gx0, bool fast, float (&v)[16]) {
+    const bool row_ok = gy >= 0 && gy < H;
+    if (fast) {
+        const F4u *src = reinterpret_cast<const F4u *>(img + (size_t)(row_ok ? gy : 0) * W + gx0);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float4 f = reinterpret_cast<const float4 *>(row)[q];
-        v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+        for (int q = 0; q < 4; q++) {
+            const F4u f = src[q];
+            v[4 * q] = row_ok ? f.x : 0.f; v[4 * q + 1] = row_ok ? f.y : 0.f; v[4 * q + 2] = row_ok ? f.z : 0.f; v[4 * q + 3] = row_ok ? f.w : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int gx = gx0 + k;
+            const bool in = row_ok && gx >= 0 && gx < W;
+            v[k] = in ? img[(size_t)gy * W + gx] : 0.f;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_loss_fwd(const float *__restrict__ x1g, const float *__restrict__ x2g, int H, int W, Win win,
                                                   float *__restrict__ m1, float *__restrict__ m2, float *__restrict__ m3,
                                                   float2 *__restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float t1[HS][TST], t2[HS][TST];
     __shared__ float h[5][HS][TS + 1];
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < HS * TST; i += 256) {
-        const int ly = i / TST, lx = i - ly * TST, gy = y0 + ly - R, gx = x0 + lx - R;
-        const bool in = lx < HS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        t1[ly][lx] = in ? x1g[plane + (size_t)gy * W + gx] : 0.f;  // zero padding, like conv2d(padding=5)
-        t2[ly][lx] = in ? x2g[plane + (size_t)gy * W + gx] : 0.f;
-    }
-    __syncthreads();
+    const float *x1p = x1g + plane, *x2p = x2g + plane;
+    const bool fast = x0 >= R && x0 + TS + R + 2 <= W;  // every 16-float span of this tile's halo rows lies inside the image row
     for (int i = tid; i < HS * XG; i += 256) {  // horizontal pass: 42 rows x 8 groups of 4 columns
         const int ly = i / XG, xg = i - ly * XG;
         float p[16], q[16];
-        load_row16(&t1[ly][4 * xg], p);
-        load_row16(&t2[ly][4 * xg], q);
+        load_row16(x1p, H, W, y0 + ly - R, x0 + 4 * xg - R, fast, p);
+        load_row16(x2p, H, W, y0 + ly - R, x0 + 4 * xg - R, fast, q);
         float pp[14], qq[14], pq[14];
 #pragma unroll
         for (int k = 0; k < 14; k++) { pp[k] = p[k] * p[k]; qq[k] = q[k] * q[k]; pq[k] = p[k] * q[k]; }
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float *__restrict__ x1g,
             m2[qi] = ds_ds1;
             m3[qi] = ds_ds12;
         }
-        l1v += in ? fabsf(t1[ty + R][tx + R] - t2[ty + R][tx + R]) : 0.f;
+        l1v += in ? fabsf(x1p[(size_t)gy * W + gx] - x2p[(size_t)gy * W + gx]) : 0.f;
         sv += in ? smap : 0.f;
     }
     const float sl = block_sum_256(l1v, red);
@@ -150,25 +160,17 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float *__restrict__ x1g,
                                                   const float *__restrict__ m2, const float *__restrict__ m3, int H, int W, Win win,
                                                   const float *__restrict__ g_out2 /* d/dL1mean, d/dSSIMmean (device) */, float inv_count,
                                                   float *__restrict__ dx1) {
-    __shared__ __attribute__((aligned(16))) float t[3][HS][TST];
     __shared__ float h[3][HS][TS + 1];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < HS * TST; i += 256) {
-        const int ly = i / TST, lx = i - ly * TST, gy = y0 + ly - R, gx = x0 + lx - R;
-        const bool in = lx < HS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t q = plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-        t[0][ly][lx] = in ? m1[q] : 0.f;
-        t[1][ly][lx] = in ? m2[q] : 0.f;
-        t[2][ly][lx] = in ? m3[q] : 0.f;
-    }
-    __syncthreads();
-    for (int i = tid; i < HS * XG; i += 256) {
+    const float *mp[3] = {m1 + plane, m2 + plane, m3 + plane};
+    const bool fast = x0 >= R && x0 + TS + R + 2 <= W;
+    for (int i = tid; i < HS * XG; i += 256) {  // horizontal pass over the three derivative maps, read straight from global memory
         const int ly = i / XG, xg = i - ly * XG;
         float v[3][16];
 #pragma unroll
-        for (int c = 0; c < 3; c++) load_row16(&t[c][ly][4 * xg], v[c]);
+        for (int c = 0; c < 3; c++) load_row16(mp[c], H, W, y0 + ly - R, x0 + 4 * xg - R, fast, v[c]);
 #pragma unroll
         for (int o = 0; o < 4; o++) {
             float a = 0.f, b = 0.f, c = 0.f;
