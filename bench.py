@@ -292,7 +292,6 @@ def main():
     # not perturb the pipeline it measures.  After the switch to that final mode >= 10 untimed steps run before anything is timed.
     # Then REPEATS blocks of EXACTLY --steps steps each are timed (barrier + synchronize on both sides, MAX over ranks); `value`,
     # `ms_per_step` are those of the MEDIAN block (all blocks are listed in `repeats_ms_per_step`). ------------------------------------
-    serial_dom_us = stages[dom_stage][0] / max(1, stages[dom_stage][1]) * 1e3  # one view at a time (calibration pass above)
     RZ.set_stage_timing(True, dom_stage)
     steps_pipelined(max(10, args.warmup, 2 * F) + 4 * F)  # also lets the clocks settle under the concurrent load
     torch.cuda.synchronize(dev)
@@ -300,10 +299,14 @@ def main():
     REPEATS = 5
     blocks = [timed(steps_pipelined, args.steps, 0, multi=True) for _ in range(REPEATS)]
     dom_live = _capi.timing_read()[dom_stage]
+    # Second timed region: the same step, EXACTLY --steps of them, one view in flight, the dominant kernel still bracketed by hipEvents on
+    # its launch stream.  The roofline takes the kernel's duration from HERE: a roofline compares a kernel that has the chip to itself
+    # with the chip's peak, and a launch that time-shares the chip with the kernels of F - 1 other views (the headline region above)
+    # has no exclusive duration -- there every launch lasts longer while the aggregate rate is higher (its duration is reported too:
+    # `headline_region`).
+    el_single = timed(step, args.steps, 5)
+    dom_excl = _capi.timing_read()[dom_stage]
     RZ.set_stage_timing(False)
-    # the roofline uses the duration measured inside the timed region (F launches overlapping: they time-share the chip, so each launch
-    # lasts longer than it does alone while the aggregate rate is higher); the `stages` table lists the one-view-at-a-time durations
-    el_single = timed(step, args.steps, 5)  # secondary: one view in flight
     elapsed = sorted(blocks)[REPEATS // 2]
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
@@ -374,7 +377,9 @@ def main():
                     pmc_src = pj.get("source")
             except Exception:  # noqa: BLE001
                 traffic = None
-        dom_us = round(dom_live[0] / max(1, dom_live[1]) * 1e3, 2) if dom == dom_stage and dom_live[1] else per_stage[dom]["avg_us"]
+        # exclusive duration: the one-view-in-flight timed region (falls back to the calibration pass if the dominant kernel changed)
+        dom_us = round(dom_excl[0] / max(1, dom_excl[1]) * 1e3, 2) if dom == dom_stage and dom_excl[1] else per_stage[dom]["avg_us"]
+        ovl_us = round(dom_live[0] / max(1, dom_live[1]) * 1e3, 2) if dom == dom_stage and dom_live[1] else None
         achieved = round(alg_bytes[dom] / (dom_us * 1e-6) / 1e9, 1)
         alg_tile = None
         if R_tile and dom in ("composite_fwd", "composite_bwd"):  # the same formula with SURVEY's 16x16-tile instance count (T = 16x16 tiles)
@@ -383,8 +388,11 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_tiles" if (dom.startswith("composite") and RZ._composite_flag()) else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_src,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": dom_us,
-                    "views_in_flight": F, "avg_launch_us_one_view_in_flight": round(serial_dom_us, 2),
-                    "frac_one_view_in_flight": round(alg_bytes[dom] / (serial_dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "measured": "hipEvents around the kernel on its launch stream over a timed region of %d steps with ONE view in flight (exclusive "
+                                "duration; profiles/r02_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % args.steps,
+                    # the same kernel inside the headline region: F views in flight, launches of different views overlap and time-share the chip
+                    "headline_region": {"views_in_flight": F, "avg_launch_us": ovl_us,
+                                        "frac": (round(alg_bytes[dom] / (ovl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if ovl_us else None)},
                     "instances": {"bin_8x8": R, "tile_16x16": R_tile},
                     "frac_with_tile_16x16_instances": (round(alg_tile / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if alg_tile else None),
                     # compositing is FP32-VALU bound, not HBM bound: one wave64 VALU instruction holds a SIMD for 4 cycles;

@@ -28,6 +28,13 @@ def test_bench_json_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    # the roofline's duration is the EXCLUSIVE one (one view in flight): a kernel of the step cannot last longer than that step, and
+    # achieved = algorithmic bytes / that duration; the duration inside the headline region (views overlapping) is listed next to it
+    step_one_view_ms = 1e3 / d["single_view_in_flight_views_per_s"]
+    assert 0 < rf["avg_launch_us"] * 1e-3 <= step_one_view_ms * 1.05
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) <= 0.01 * rf["achieved"] + 0.1
+    hr = rf["headline_region"]
+    assert hr["views_in_flight"] >= 1 and (hr["avg_launch_us"] is None or hr["avg_launch_us"] > 0)
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k

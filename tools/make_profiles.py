@@ -10,19 +10,27 @@ def kname(n):
 
 
 def main(d, tag):
-    # ---- kernel stats
-    rows = []
-    for fn in glob.glob(os.path.join(d, "trace", "*kernel_stats.csv")):
-        rows = list(csv.DictReader(open(fn)))
-    lines = ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --no-cpu-baseline` (the driver's command, shorter), MI355X",
-             "# bench.py renders 6 views concurrently in its headline region (one HIP stream each): the launches of different views overlap and",
-             "# time-share the chip, so a kernel's average duration here mixes its one-view-at-a-time launches (calibration, secondary legs)",
-             "# with the longer overlapped ones; bench.py reports both (`roofline.avg_launch_us`, `roofline.avg_launch_us_one_view_in_flight`).",
-             "", "| kernel | calls | total_us | avg_us | min_us | max_us | % |", "|---|---|---|---|---|---|---|"]
-    for r in rows[:28]:
-        lines.append("| %s | %s | %.1f | %.2f | %.2f | %.2f | %s |" % (kname(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
-                                                                       float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-    open(os.path.join(d, "kernel_stats.md"), "w").write("\n".join(lines) + "\n")
+    # ---- kernel stats: the default command (views overlapping) and the one-view-in-flight command (exclusive durations)
+    def stats_table(sub, header, out_name):
+        rows = []
+        for fn in glob.glob(os.path.join(d, sub, "*kernel_stats.csv")):
+            rows = list(csv.DictReader(open(fn)))
+        if not rows:
+            return
+        lines = header + ["", "| kernel | calls | total_us | avg_us | min_us | max_us | % |", "|---|---|---|---|---|---|---|"]
+        for r in rows[:28]:
+            lines.append("| %s | %s | %.1f | %.2f | %.2f | %.2f | %s |" % (kname(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
+                                                                           float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+        open(os.path.join(d, out_name), "w").write("\n".join(lines) + "\n")
+
+    stats_table("trace", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --no-cpu-baseline` (the driver's command, shorter), MI355X",
+                          "# bench.py renders 6 views concurrently in its headline region (one HIP stream each): the launches of different views overlap and",
+                          "# time-share the chip, so a kernel's average duration here mixes its one-view-at-a-time launches (calibration, one-view timed region,",
+                          "# secondary legs) with the longer overlapped ones.  The exclusive durations -- what `roofline.avg_launch_us` is -- are in",
+                          "# %s_kernel_stats_one_view.md; `roofline.headline_region.avg_launch_us` is the overlapped duration." % tag], "kernel_stats.md")
+    stats_table("trace1", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --no-cpu-baseline --inflight 1`, MI355X: ONE view in flight,",
+                           "# every launch has the chip to itself.  These are the exclusive kernel durations: `roofline.avg_launch_us` of bench.py (hipEvents on",
+                           "# the launch stream over its one-view timed region) and the `stages` table agree with the avg_us column below."], "kernel_stats_one_view.md")
     # ---- pmc
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in sorted(glob.glob(os.path.join(d, "pmc_*", "*counter_collection.csv"))):
