@@ -108,6 +108,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     uint32_t *bin_cursor = reinterpret_cast<uint32_t *>(at(workspace, L.bin_cursor));
     uint32_t *wg_order = reinterpret_cast<uint32_t *>(at(workspace, L.wg_order));
     uint4 *scan_part = reinterpret_cast<uint4 *>(at(workspace, L.scan_part));
+    uint32_t *order_hint = reinterpret_cast<uint32_t *>(at(workspace, L.order_hint));
     GsrSplat *splats = reinterpret_cast<GsrSplat *>(at(workspace, L.splats));
     uint32_t *hitmask = reinterpret_cast<uint32_t *>(at(workspace, L.hitmask));
     uint32_t *wg_tab = reinterpret_cast<uint32_t *>(at(workspace, L.wg_tab));
@@ -144,12 +145,12 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     {
         StageTimer t(flags, GSR_STAGE_SCAN, s);
         gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, L.bx, L.by, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
-                        (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
+                        (flags & GSR_FLAG_NO_LARGE_SORT) != 0, order_hint, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, s);
+        gsr_launch_scatter(P, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, order_hint, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {

@@ -56,30 +56,47 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum /*[1
     return woff + x - v;
 }
 
-// phase A: per block of 1024 indices -> {sum of counts (bins in image order), busy | idle << 16 bins among the block's indices in
-// WORK order (tiled_bin), max count}
-__global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part, int NB, int bx, int by) {
-    __shared__ uint32_t red[3][SB / 64];
+// Work classes of a bin in the compositing / sort order, by the length of its list relative to the longest list the previous forward
+// on this workspace saw (hint): class 0 = more than 1/2 of it, 1 = more than 1/4, 2 = any other busy bin, 3 = idle.  The classes are
+// dispatched in that order: a bin is ONE wave's sequential job and a SIMD gets only ~5 of them per kernel, so a 900-entry list that
+// starts late is what the other SIMDs end up waiting for (longest-processing-time-first, coarsely).  Two packed counters:
+// w0 = class 0 | class 1 << 16, w1 = class 2 | idle << 16 (each count <= 1024 per scan block).
+// The order is a performance hint only (every bin is handled exactly once whatever its position), so the threshold may be anything:
+// it comes from a word in the workspace that k_scatter refreshes after the scan (uninitialised the first time: harmless).
+__device__ __forceinline__ int work_class(int wb, uint32_t wc, uint32_t hint) {
+    return wb < 0 ? -1 : (wc > (hint >> 1) ? 0 : (wc > (hint >> 2) ? 1 : (wc > 0u ? 2 : 3)));
+}
+__device__ __forceinline__ uint32_t class_w0(int cls) { return cls == 0 ? 1u : (cls == 1 ? 0x10000u : 0u); }
+__device__ __forceinline__ uint32_t class_w1(int cls) { return cls == 2 ? 1u : (cls == 3 ? 0x10000u : 0u); }
+
+// phase A: per block of 1024 indices -> part[2 blk] = {sum of counts (bins in image order), w0 of the block's indices in WORK order
+// (tiled_bin), max count, -}, part[2 blk + 1].x = their w1
+__global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part, int NB, int bx, int by,
+                                               const uint32_t *__restrict__ order_hint) {
+    __shared__ uint32_t red[4][SB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x * SB + tid;
+    const uint32_t hint = *order_hint;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
     const int wb = tiled_bin((uint32_t)b, bx, by);
     const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] : 0u;
-    const uint32_t busy = wc > 0 ? 1u : (wb >= 0 ? 0x10000u : 0u);  // one compositing workgroup (= one wave) per bin
-    uint32_t s = c, nb = busy, mx = c;
+    const int cls = work_class(wb, wc, hint);
+    uint32_t s = c, nb = class_w0(cls), ni = class_w1(cls), mx = c;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         s += __shfl_xor(s, d, 64);
         nb += __shfl_xor(nb, d, 64);
+        ni += __shfl_xor(ni, d, 64);
         const uint32_t y = __shfl_xor(mx, d, 64);
         mx = y > mx ? y : mx;
     }
-    if (lane == 0) { red[0][wid] = s; red[1][wid] = nb; red[2][wid] = mx; }
+    if (lane == 0) { red[0][wid] = s; red[1][wid] = nb; red[2][wid] = mx; red[3][wid] = ni; }
     __syncthreads();
     if (tid == 0) {
-        uint32_t ts = 0, tb = 0, tm = 0;
-        for (int w = 0; w < SB / 64; w++) { ts += red[0][w]; tb += red[1][w]; tm = red[2][w] > tm ? red[2][w] : tm; }
-        part[blockIdx.x] = make_uint4(ts, tb, tm, 0u);
+        uint32_t ts = 0, tb = 0, tm = 0, ti = 0;
+        for (int w = 0; w < SB / 64; w++) { ts += red[0][w]; tb += red[1][w]; tm = red[2][w] > tm ? red[2][w] : tm; ti += red[3][w]; }
+        part[2 * blockIdx.x] = make_uint4(ts, tb, tm, 0u);
+        part[2 * blockIdx.x + 1] = make_uint4(ti, 0u, 0u, 0u);
     }
 }
 
@@ -95,14 +112,18 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
                                                uint32_t *__restrict__ wg_order, int NB, int bx, int by, int nblocks, int64_t cap,
                                                GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
-                                               uint32_t *__restrict__ host_hdr, uint32_t host_seq, int no_large_sort) {
+                                               uint32_t *__restrict__ host_hdr, uint32_t host_seq, int no_large_sort,
+                                               const uint32_t *__restrict__ order_hint) {
     __shared__ uint32_t wsum[SB / 64];
     __shared__ uint4 sp[FUSED ? GSR_SCAN_FUSE_MAX : 1];
+    __shared__ uint32_t sp_idle[FUSED ? GSR_SCAN_FUSE_MAX : 1];
+    const uint32_t hint = *order_hint;  // the same word for every block of this launch: it is only rewritten by k_scatter
     const int tid = threadIdx.x;
     const int b = blockIdx.x * SB + tid;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
     const int wb = tiled_bin((uint32_t)b, bx, by);  // the bin this thread places in the work order
     const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] : 0u;
+    const int cls = work_class(wb, wc, hint);
     // block 0 also owns the per-Gaussian slot prefix (training) and the header.  Neither depends on the other blocks' bins, so the
     // slot scan runs first -- under the wait for their partials -- and the header leaves (also towards the host) as soon as the
     // totals are known, before this block scans its own bins.
@@ -123,42 +144,46 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     };
     if (!FUSED) slot_scan();
     if (FUSED) {
-        __shared__ uint32_t red[3][SB / 64];
+        __shared__ uint32_t red[4][SB / 64];
         const int lane = tid & 63, wid = tid >> 6;
-        uint32_t s = c, nb = wc > 0 ? 1u : (wb >= 0 ? 0x10000u : 0u), mx = c;  // nb: busy | idle << 16 (each <= 1024)
+        uint32_t s = c, nb = class_w0(cls), ni = class_w1(cls), mx = c;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             s += __shfl_xor(s, d, 64);
             nb += __shfl_xor(nb, d, 64);
+            ni += __shfl_xor(ni, d, 64);
             const uint32_t y = __shfl_xor(mx, d, 64);
             mx = y > mx ? y : mx;
         }
-        if (lane == 0) { red[0][wid] = s; red[1][wid] = nb; red[2][wid] = mx; }
+        if (lane == 0) { red[0][wid] = s; red[1][wid] = nb; red[2][wid] = mx; red[3][wid] = ni; }
         __syncthreads();
         if (tid == 0) {
-            uint32_t ts = 0, tb = 0, tm = 0;
-            for (int w = 0; w < SB / 64; w++) { ts += red[0][w]; tb += red[1][w]; tm = red[2][w] > tm ? red[2][w] : tm; }
-            uint32_t *me = reinterpret_cast<uint32_t *>(part + blockIdx.x);
-            me[0] = ts; me[1] = tb; me[2] = tm;
+            uint32_t ts = 0, tb = 0, tm = 0, ti = 0;
+            for (int w = 0; w < SB / 64; w++) { ts += red[0][w]; tb += red[1][w]; tm = red[2][w] > tm ? red[2][w] : tm; ti += red[3][w]; }
+            uint32_t *me = reinterpret_cast<uint32_t *>(part + 2 * blockIdx.x);  // {sum, w0, max, flag | w1, -, -, -}
+            me[0] = ts; me[1] = tb; me[2] = tm; me[4] = ti;
             __hip_atomic_store(me + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ready flag (zeroed by the forward's memset)
         }
         slot_scan();  // after this block's partial is out, before the others' are needed
         if (tid < nblocks) {  // wait for every block's partial (all blocks are resident: nblocks <= GSR_SCAN_FUSE_MAX)
-            uint32_t *other = reinterpret_cast<uint32_t *>(part + tid);
+            uint32_t *other = reinterpret_cast<uint32_t *>(part + 2 * tid);
             while (__hip_atomic_load(other + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
             sp[tid] = make_uint4(__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                                  __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                                  __hip_atomic_load(other + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1u);
+            sp_idle[tid] = __hip_atomic_load(other + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
-    uint32_t pre_sum = 0, pre_busy = 0, pre_idle = 0, tot_busy = 0, tot_max = 0;
+    uint32_t pre_sum = 0, pre[4] = {0, 0, 0, 0}, tot[3] = {0, 0, 0}, tot_max = 0;  // pre / tot: per work class (tot: the three busy ones)
     uint64_t tot_sum = 0;  // 64-bit: a total beyond 2^32 must read as an overflow, not wrap below the capacity
     for (int i = 0; i < nblocks; i++) {  // a handful of uint4
-        const uint4 p = FUSED ? sp[i] : part[i];
-        if (i < (int)blockIdx.x) { pre_sum += p.x; pre_busy += p.y & 0xffffu; pre_idle += p.y >> 16; }
-        tot_sum += p.x; tot_busy += p.y & 0xffffu; tot_max = p.z > tot_max ? p.z : tot_max;
+        const uint4 p = FUSED ? sp[i] : part[2 * i];
+        const uint32_t w1 = FUSED ? sp_idle[i] : part[2 * i + 1].x;
+        if (i < (int)blockIdx.x) { pre_sum += p.x; pre[0] += p.y & 0xffffu; pre[1] += p.y >> 16; pre[2] += w1 & 0xffffu; pre[3] += w1 >> 16; }
+        tot_sum += p.x; tot[0] += p.y & 0xffffu; tot[1] += p.y >> 16; tot[2] += w1 & 0xffffu; tot_max = p.z > tot_max ? p.z : tot_max;
     }
+    const uint32_t tot_busy = tot[0] + tot[1] + tot[2];
     if (blockIdx.x == 0 && tid == 0) {
         bin_offset[NB] = (uint32_t)tot_sum;
         hdr->num_rendered = tot_sum;
@@ -185,18 +210,28 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         bin_offset[b] = off;
         bin_cursor[(size_t)b * GSR_CPAD] = off;
     }
-    // work-ordered workgroup list: busy bins first, in patch order (tiled_bin) inside each class; both ranks from one scan
-    const bool busy = wc > 0;
+    // work-ordered workgroup list: the classes in order (longest lists first, idle bins last), patch order (tiled_bin) inside each class
     uint32_t blk_tot;
-    const uint32_t rank = block_exscan(busy ? 1u : (wb >= 0 ? 0x10000u : 0u), wsum, &blk_tot);
-    if (wb >= 0) wg_order[busy ? pre_busy + (rank & 0xffffu) : tot_busy + pre_idle + (rank >> 16)] = (uint32_t)wb;
+    const uint32_t r0 = block_exscan(class_w0(cls), wsum, &blk_tot);
+    const uint32_t r1 = block_exscan(class_w1(cls), wsum, &blk_tot);
+    if (wb >= 0) {
+        const uint32_t pos = cls == 0 ? pre[0] + (r0 & 0xffffu)
+                           : cls == 1 ? tot[0] + pre[1] + (r0 >> 16)
+                           : cls == 2 ? tot[0] + tot[1] + pre[2] + (r1 & 0xffffu)
+                                      : tot_busy + pre[3] + (r1 >> 16);
+        wg_order[pos] = (uint32_t)wb;
+    }
 }
 
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
                                                             const uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
                                                             const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
-                                                            const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid) {
+                                                            const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid,
+                                                            uint32_t *__restrict__ order_hint) {
     if (hdr->overflow) return;
+    // the longest list of THIS forward becomes the next forward's threshold for "long" lists (k_scan_a/b work_class); written here,
+    // after every block of the scan has read the old value (stream order)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *order_hint = hdr->max_tile_count;
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t lo = 0, hi = 0, mask = 0;
     uint64_t key = 0;
@@ -425,24 +460,24 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
-                     hipStream_t s) {
+                     const uint32_t *order_hint, hipStream_t s) {
     const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB: ragged patches at the grid edge)
     const int nblocks = ((NT > NB ? NT : NB) + SB - 1) / SB;
     if (nblocks <= GSR_SCAN_FUSE_MAX) {
         hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap,
-                           hdr, gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0);
+                           hdr, gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0, order_hint);
         return;
     }
-    hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB, bx, by);
+    hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB, bx, by, order_hint);
     hipLaunchKernelGGL(k_scan_b<false>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap, hdr,
-                       gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0);
+                       gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0, order_hint);
 }
 
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s) {
+                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, uint32_t *order_hint, hipStream_t s) {
     if (P <= 0) return;
     hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr,
-                       goff, gpart, inst_valid);
+                       goff, gpart, inst_valid, order_hint);
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,

@@ -65,7 +65,7 @@ struct __attribute__((aligned(32))) GsrGradAcc {
 static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte sector");
 
 struct GsrLayout {
-    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, hitmask, wg_tab, keys, point_list, final_T, n_contrib;
+    size_t header, bin_count, bin_offset, bin_cursor, wg_order, order_hint, scan_part, splats, hitmask, wg_tab, keys, point_list, final_T, n_contrib;
     size_t total_fwd;  // bytes a forward-only workspace needs
     size_t goff, gscan_part, inst_valid, inst_dop, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
@@ -95,11 +95,12 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.NB > 0 ? L.NB : 1), c = (size_t)(cap > 0 ? cap : 1);
     const size_t npix = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
     L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + scan_part + bin_count are zeroed by ONE memset
-    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 16);
+    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 32);  // two uint4 per scan block
     L.bin_count = o;  o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.bin_offset = o; o = gsr_align_up(o + (t + 1) * 4);
     L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
+    L.order_hint = o; o = gsr_align_up(o + 4);  // longest list of the previous forward on this workspace (never cleared: a hint)
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
     L.hitmask = o;    o = gsr_align_up(o + p * 4);
     L.wg_tab = o;     o = gsr_align_up(o + ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
@@ -315,9 +316,9 @@ void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hi
                            hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
-                     hipStream_t s);
+                     const uint32_t *order_hint, hipStream_t s);
 void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s);
+                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, uint32_t *order_hint, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s);
 void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
