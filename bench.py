@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--gaussians", type=int, default=600_000)
     ap.add_argument("--inflight", type=int, default=6, help="independent views rendered concurrently per GPU (one RasterSession + HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip every secondary leg (autograd module, forward only, deferred check, stage-2 path, HIP graph, CPU rows): with --inflight 1 "
+                         "every kernel launch of the run then has the chip to itself (tools/prof_r02.sh profiles that mode for the exclusive durations)")
     ap.add_argument("--graph-leg", action="store_true", help="(internal) time HIP-graph replays of the fwd+bwd step and print one JSON line")
     args = ap.parse_args()
     if args.graph_leg:
@@ -314,12 +317,14 @@ def main():
 
     # secondary numbers (outside the headline region): the same step through the autograd drop-in module, forward only, and the
     # non-blocking check mode
-    el_api = timed(fwd_bwd, args.steps, 5)
-    el_fwd = timed(fwd_only, args.steps, 3)
-    os.environ["GPSGS_CHECK"] = "deferred"
-    el_def = timed(fwd_bwd, args.steps, 3)
-    el_fwd_def = timed(fwd_only, args.steps, 3)
-    os.environ["GPSGS_CHECK"] = "sync"
+    el_api = el_fwd = el_def = el_fwd_def = None
+    if not args.headline_only:
+        el_api = timed(fwd_bwd, args.steps, 5)
+        el_fwd = timed(fwd_only, args.steps, 3)
+        os.environ["GPSGS_CHECK"] = "deferred"
+        el_def = timed(fwd_bwd, args.steps, 3)
+        el_fwd_def = timed(fwd_only, args.steps, 3)
+        os.environ["GPSGS_CHECK"] = "sync"
     torch.cuda.synchronize(dev)
 
     # SURVEY.md section 8(d) counts instances on upstream's 16x16 tiles: the same view's tile-instance count, from the radii and the
@@ -336,7 +341,7 @@ def main():
         R_tile = None
 
     # ---- secondary: the hot path inside one stage-2 training iteration (BASELINE config 4: batch = 4 stereo pairs per GPU) ----
-    stage2 = stage2_leg(args, s, dev, rank, local_rank, world, D, timed)
+    stage2 = None if args.headline_only else stage2_leg(args, s, dev, rank, local_rank, world, D, timed)
 
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------------
     NB = (((W + 7) // 8 + 3) // 4 * 4) * ((H + 7) // 8)  # 8x8-pixel bins (one wave64 each), DESIGN.md section 2
@@ -401,7 +406,7 @@ def main():
 
     # ---- CPU baseline: the fp32 oracle on the host cores (rank 0, N=1 only), bounded sample ------------------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.headline_only:
         from oracle.gsr_oracle import OracleRasterizer
         o = OracleRasterizer("f32")
         dp = gout.cpu().numpy()
@@ -418,7 +423,7 @@ def main():
     # ---- second CPU row: a port of the reference's Taichi point splat (lib/TaichiRender.py:13-24; taichi itself is not installed,
     # SURVEY.md section 8d): forward-only z-buffer splat of the same view's points, sequential like its deterministic tie rule ----
     cpu_splat = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.headline_only:
         try:
             import ctypes as C
             from oracle import gsr_oracle as GO
@@ -448,7 +453,7 @@ def main():
 
     # ---- secondary: the same step replayed from a HIP graph (child process; see graph_leg) --------------------------------
     graph_res = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         import subprocess
         try:
             cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-leg", "--steps", str(args.steps), "--res", str(args.res),
@@ -460,6 +465,7 @@ def main():
             graph_res = {"error": repr(e)[:200]}
 
     if rank == 0:
+        rate = lambda el: round(world * args.steps / el, 2) if el else None  # noqa: E731
         cfg_name = ("BASELINE config 2" if (args.res, args.gaussians, W) == (1024, 600000, 1024) else
                     "BASELINE config 2 rendered at 2048^2 (use_hr_img)" if (args.res, args.gaussians, W) == (1024, 600000, 2048) else
                     "BASELINE config 5" if (args.res, args.gaussians, W) == (2048, 2400000, 2048) else "non-BASELINE workload (parity / contract test size)")
@@ -476,10 +482,10 @@ def main():
                        "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)"},
             "repeats_ms_per_step": [round(x / args.steps * 1e3, 4) for x in blocks],
             "single_view_in_flight_views_per_s": round(world * args.steps / el_single, 2),
-            "autograd_api_views_per_s": round(world * args.steps / el_api, 2),
+            "autograd_api_views_per_s": rate(el_api),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
-            "forward_only_views_per_s": round(world * args.steps / el_fwd, 2),
-            "deferred_check_views_per_s": {"fwd_bwd": round(world * args.steps / el_def, 2), "fwd": round(world * args.steps / el_fwd_def, 2)},
+            "forward_only_views_per_s": rate(el_fwd),
+            "deferred_check_views_per_s": {"fwd_bwd": rate(el_def), "fwd": rate(el_fwd_def)},
             "stages": per_stage,
             "stage2_path": stage2,
             "hip_graph_replay": graph_res,

@@ -28,7 +28,7 @@ def main(d, tag):
                           "# time-share the chip, so a kernel's average duration here mixes its one-view-at-a-time launches (calibration, one-view timed region,",
                           "# secondary legs) with the longer overlapped ones.  The exclusive durations -- what `roofline.avg_launch_us` is -- are in",
                           "# %s_kernel_stats_one_view.md; `roofline.headline_region.avg_launch_us` is the overlapped duration." % tag], "kernel_stats.md")
-    stats_table("trace1", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --no-cpu-baseline --inflight 1`, MI355X: ONE view in flight,",
+    stats_table("trace1", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --no-cpu-baseline --inflight 1 --headline-only`, MI355X: ONE view in flight,",
                            "# every launch has the chip to itself.  These are the exclusive kernel durations: `roofline.avg_launch_us` of bench.py (hipEvents on",
                            "# the launch stream over its one-view timed region) and the `stages` table agree with the avg_us column below."], "kernel_stats_one_view.md")
     # ---- pmc
