@@ -12,7 +12,8 @@
 //                map value and the three partial-derivative maps the backward needs are formed in registers, |x1 - x2|
 //                is added, and per-workgroup partial sums are written (deterministic two-level reduction, no atomics);
 //   k_loss_reduce  sums the partials in double -> {mean L1, mean SSIM};
-//   k_loss_bwd   same tiling: separable filter of the three derivative maps, then
+//   k_loss_bwd   same tiling, but the 42x42 halo of the three derivative maps IS staged in LDS (read from global directly, as the
+//                forward does, the twelve unaligned 16-byte loads per item made it slower: 125 -> 159 us at [4,3,1024,1024]); then
 //                dL/dpred = gL1 * sign(x1 - x2) / N + gSSIM * (F*M1 + 2 x1 F*M2 + x2 F*M3) / N.
 // HBM traffic: forward reads 8 B and writes 12 B per element, backward reads 20 B and writes 4 B -- against roughly 30
 // full-tensor passes in the eager version.
@@ -21,6 +22,7 @@
 namespace {
 
 constexpr int TS = 32, R = 5, HS = TS + 2 * R;  // tile side, window radius, halo side (42)
+constexpr int TST = HS + 2;                     // row stride of a staged tile (backward): 44 floats, so 16-byte row reads stay aligned
 constexpr int XG = TS / 4;                      // every thread produces 4 ADJACENT outputs per pass from a sliding window:
                                                 // 14 LDS values feed 4 x 11 taps (3.4x fewer LDS reads than one output per thread)
 
@@ -38,6 +40,14 @@ __device__ __forceinline__ float block_sum_256(float v, float *red /*[4]*/) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// 16 consecutive floats of a row staged in LDS (the sliding window uses the first 14)
+__device__ __forceinline__ void load_row16_lds(const float *row, float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 f = reinterpret_cast<const float4 *>(row)[q];
+        v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+    }
+}
 struct __attribute__((aligned(4))) F4u {  // 16 bytes at dword alignment (gfx950 global_load_dwordx4 needs no more)
     float x, y, z, w;
 };
@@ -160,17 +170,25 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float *__restrict__ x1g,
                                                   const float *__restrict__ m2, const float *__restrict__ m3, int H, int W, Win win,
                                                   const float *__restrict__ g_out2 /* d/dL1mean, d/dSSIMmean (device) */, float inv_count,
                                                   float *__restrict__ dx1) {
+    __shared__ __attribute__((aligned(16))) float t[3][HS][TST];
     __shared__ float h[3][HS][TS + 1];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    const float *mp[3] = {m1 + plane, m2 + plane, m3 + plane};
-    const bool fast = x0 >= R && x0 + TS + R + 2 <= W;
-    for (int i = tid; i < HS * XG; i += 256) {  // horizontal pass over the three derivative maps, read straight from global memory
+    for (int i = tid; i < HS * TST; i += 256) {
+        const int ly = i / TST, lx = i - ly * TST, gy = y0 + ly - R, gx = x0 + lx - R;
+        const bool in = lx < HS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t q = plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+        t[0][ly][lx] = in ? m1[q] : 0.f;
+        t[1][ly][lx] = in ? m2[q] : 0.f;
+        t[2][ly][lx] = in ? m3[q] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * XG; i += 256) {
         const int ly = i / XG, xg = i - ly * XG;
         float v[3][16];
 #pragma unroll
-        for (int c = 0; c < 3; c++) load_row16(mp[c], H, W, y0 + ly - R, x0 + 4 * xg - R, fast, v[c]);
+        for (int c = 0; c < 3; c++) load_row16_lds(&t[c][ly][4 * xg], v[c]);
 #pragma unroll
         for (int o = 0; o < 4; o++) {
             float a = 0.f, b = 0.f, c = 0.f;
