@@ -48,11 +48,15 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
                 const lanemask_t sat = __ballot(test_T < 0.0001f);
                 st.active &= ~(valid & sat);
                 const bool use = __builtin_amdgcn_inverse_ballot_w64(valid & ~sat);
-                const float w = use ? alpha * st.T : 0.f;
+                // the blend weight alpha T as the transmittance the splat takes away, T - T (1 - alpha): one subtraction after the
+                // select (exactly 0 for a pair that is not blended) instead of a product and a second select.  It differs from the
+                // rounded product by at most 1 ulp of T (6e-8 T absolute) -- the size of the accumulation's own rounding
+                const float T_next = use ? test_T : st.T;
+                const float w = st.T - T_next;
                 st.C0 += c.y * w;
                 st.C1 += c.z * w;
                 st.C2 += c.w * w;
-                st.T = use ? test_T : st.T;
+                st.T = T_next;
                 if (KEEP) st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
             }
         }
