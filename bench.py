@@ -296,7 +296,7 @@ def main():
     # Then REPEATS blocks of EXACTLY --steps steps each are timed (barrier + synchronize on both sides, MAX over ranks); `value`,
     # `ms_per_step` are those of the MEDIAN block (all blocks are listed in `repeats_ms_per_step`). ------------------------------------
     RZ.set_stage_timing(True, dom_stage)
-    steps_pipelined(max(10, args.warmup, 2 * F) + 4 * F)  # also lets the clocks settle under the concurrent load
+    steps_pipelined(max(10, args.warmup, 2 * F) + 4 * F + args.steps)  # untimed; also lets the clocks settle under the concurrent load (one block's worth)
     torch.cuda.synchronize(dev)
     _capi.timing_read()
     REPEATS = 5
