@@ -25,6 +25,7 @@ Host-side design notes (MI355X-first, not a translation of upstream's C++ glue):
 import ctypes as C
 import os
 import threading
+import time
 from typing import NamedTuple
 
 import torch
@@ -174,11 +175,13 @@ def _wait_notify(w32, seq, cur_stream):
     n = 0
     while int(w32[7]) != seq:
         n += 1
-        if n & 0x3ff == 0 and cur_stream.query():  # the stream drained without the store: surface the device error
-            if int(w32[7]) == seq:
-                break
-            torch.cuda.synchronize()
-            raise RuntimeError("gps_gaussian_amd: the rasteriser forward finished without publishing its header")
+        if n & 0x3ff == 0:  # ~every 100 us of spinning (the store normally lands within the first ~40 us)
+            if cur_stream.query():  # the stream drained without the store: surface the device error
+                if int(w32[7]) == seq:
+                    break
+                torch.cuda.synchronize()
+                raise RuntimeError("gps_gaussian_amd: the rasteriser forward finished without publishing its header")
+            time.sleep(0)  # a long wait (the stream is busy with earlier work): give the core to another thread of this rank
 
 
 # ---- several forwards in flight (pts2render: one stream per sample of the batch) ---------------------------------------------------
