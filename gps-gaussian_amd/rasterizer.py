@@ -181,7 +181,8 @@ def _wait_notify(w32, seq, cur_stream):
                     break
                 torch.cuda.synchronize()
                 raise RuntimeError("gps_gaussian_amd: the rasteriser forward finished without publishing its header")
-            time.sleep(0)  # a long wait (the stream is busy with earlier work): give the core to another thread of this rank
+            if n & 0x3fff == 0:
+                time.sleep(0)  # a very long wait (> ~1.5 ms: the stream is backed up): give the core to another thread of this rank
 
 
 # ---- several forwards in flight (pts2render: one stream per sample of the batch) ---------------------------------------------------
