@@ -113,6 +113,17 @@ class _RenderBatch(torch.autograd.Function):
         for i in range(bs):
             if side[i] is not cur:
                 cur.wait_stream(side[i])
+        # the packed inputs go through save_for_backward (autograd then notices an in-place change between forward and backward); the
+        # per-view holders keep only what is not an input: camera matrices, background, radii, workspace.  (The per-view tensors the
+        # forward used are plain row slices of the packed inputs -- pack_views hands out contiguous fp32 -- and are re-sliced in the
+        # backward; should a slice ever have been converted on the way in, its holder keeps the converted tensors instead.)
+        packed = (xyz, rgb, opacity, scale, rot)  # order of _forward_impl's saved tuple: m3, col, opa, sca, rot
+        for i, h in enumerate(views):
+            a, b = offs[i], offs[i + 1]
+            same = all(sv.data_ptr() == t[a:b].data_ptr() and sv.numel() == t[a:b].numel() for sv, t in zip(h.saved[:5], packed))
+            h.tail, h.own = h.saved[5:], (None if same else h.saved[:5])
+            h.saved = None
+        ctx.save_for_backward(xyz, rgb, rot, scale, opacity)
         ctx.views, ctx.offs, ctx.side = views, offs, side
         ctx.shapes = tuple(tuple(t.shape) for t in (xyz, rgb, rot, scale, opacity))
         ctx.set_materialize_grads(False)
@@ -123,6 +134,7 @@ class _RenderBatch(torch.autograd.Function):
         if gout is None:
             return (None,) * 7
         views, offs, side = ctx.views, ctx.offs, ctx.side
+        xyz, rgb, rot, scale, opacity = ctx.saved_tensors
         dev = gout.device
         g = gout.detach().to(dtype=torch.float32).contiguous()
         # one gradient buffer per packed tensor; every view's backward writes its own rows, rows behind offs[-1] (the unused tail of
@@ -133,8 +145,9 @@ class _RenderBatch(torch.autograd.Function):
             a, b = offs[i], offs[i + 1]
             if side[i] is not cur:
                 side[i].wait_stream(cur)
+            ins = h.own if h.own is not None else (xyz[a:b], rgb[a:b], opacity[a:b].reshape(-1), scale[a:b], rot[a:b])
             with torch.cuda.stream(side[i]):  # (a workspace replaced by the overflow repair is picked up from h.ws_box in there)
-                _RZ._backward_impl(h, h.saved, g[i], (d_xyz[a:b], d_rgb[a:b], d_op[a:b], d_scale[a:b], d_rot[a:b]))
+                _RZ._backward_impl(h, tuple(ins) + tuple(h.tail), g[i], (d_xyz[a:b], d_rgb[a:b], d_op[a:b], d_scale[a:b], d_rot[a:b]))
         for i in range(len(views)):
             if side[i] is not cur:
                 cur.wait_stream(side[i])
