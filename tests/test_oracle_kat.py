@@ -41,6 +41,26 @@ def test_backward_matches_independent_autograd(seed, W, H, n, scale):
         np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
 
 
+@pytest.mark.parametrize("seed,W,H,n,scale,zr", [(11, 64, 64, 400, 0.3, (1.0, 3.0)), (12, 57, 23, 300, 0.004, (0.25, 0.8)),
+                                                   (13, 24, 72, 350, 0.05, (0.21, 9.0)), (14, 80, 48, 500, 0.6, (2.0, 2.2)),
+                                                   (15, 16, 16, 250, 0.1, (0.5, 1.5)), (16, 96, 96, 800, 0.02, (0.4, 5.0))])
+def test_backward_matches_independent_autograd_sweep(seed, W, H, n, scale, zr):
+    """The same pin over screen-filling and sub-pixel splats, a depth range that starts at the near plane, nearly coplanar layers
+    (many pixels saturate: the T < 1e-4 stop and the 0.99 clamp are active) and non-square images, with exactly-zero and
+    exactly-one opacities mixed in."""
+    g = S.make_uniform_cloud(n, W, H, seed=seed, scale_med=scale, z_range=zr, behind_frac=0.1)
+    g["opacities"][:5] = 0.0
+    g["opacities"][5:25] = 1.0
+    dpix = np.random.default_rng(seed).standard_normal((3, H, W))
+    o, img, radii = oracle_render(g, "f64")
+    gr = o.backward(dpix)
+    img2, radii2, gr2 = grads_ref(g, W, H, g["tanfovx"], g["tanfovy"], dpix)
+    assert (radii == radii2).all() and (radii > 0).sum() > n // 4
+    np.testing.assert_allclose(img, img2, atol=1e-12)
+    for k in gr:
+        np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
+
+
 @pytest.mark.parametrize("seed,W,H,n,mod", [(3, 128, 128, 2000, 1.0), (4, 96, 80, 700, 0.5)])
 def test_backward_matches_independent_autograd_with_the_fov_clamp_active(seed, W, H, n, mod):
     """Same pin on the branches the uniform cloud leaves cold: general (rotated + translated) view matrix, centres far outside the
