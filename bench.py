@@ -91,6 +91,8 @@ def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, st
     el = timed(step, steps, 2)
     return {"iters_per_s": round(steps / el, 2), "stereo_pairs_per_s": round(world * batch * steps / el, 1), "ms_per_iter": round(el / steps * 1e3, 3),
             "batch_per_gpu": batch, "n_gpus": world, "render": "%dx%d" % (rres, rres),
+            "allreduce": ("%s, world %d%s" % (dist.get_backend(), dist.get_world_size(), " (forced: GPSGS_DIST_FORCE=1)" if D.forced() and world == 1 else "")
+                          if dist.is_initialized() else "none (one rank, no process group)"),
             "includes": "pts2render (fused pack + %d raster forwards as one autograd node, one HIP stream per sample) + L1/SSIM loss + backward to the per-pixel maps + mean all-reduce of "
                         "20.6 MB of network gradients (RCCL); networks not executed" % batch}
 
@@ -166,6 +168,28 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    # ---- `python bench.py --gpus N` (no torchrun around it): become N ranks.  The reference has no launcher at all
+    # (/root/reference/train_stage2.py:27-55 is single-process), so this is the whole multi-GPU entry: one process per GPU, rendezvous on
+    # 127.0.0.1, RCCL underneath.  Under `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is already set and must agree.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus and os.environ.get("GPSGS_BENCH_SINGLE_DEVICE") != "1":
+            raise SystemExit("bench.py: --gpus %d but this node exposes %d GPU(s) (set GPSGS_BENCH_SINGLE_DEVICE=1 to put every rank on device 0: "
+                             "a functional test of the multi-rank path, not a measurement)" % (args.gpus, have))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execvpe(sys.executable, cmd, dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s rank(s) (WORLD_SIZE); pass the same N to both" % (args.gpus, env_world))
 
     import gps_gaussian_amd  # noqa: F401
     from gps_gaussian_amd import _capi, synthetic as S

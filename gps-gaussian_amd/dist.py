@@ -17,10 +17,16 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def forced():
+    """GPSGS_DIST_FORCE=1: initialise the process group and issue the exchange-step collectives even at world size 1 -- the way a 1-GPU box
+    exercises RCCL itself (communicator set-up + a 20.6 MB all-reduce kernel) instead of skipping it."""
+    return os.environ.get("GPSGS_DIST_FORCE") == "1"
+
+
 def init(backend=None, device=None):
     """Initialise the default process group from the torchrun environment.  Returns (rank, local_rank, world)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -82,7 +88,7 @@ class GradAllReducer:
 
     @torch.no_grad()
     def __call__(self):
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not (dist.is_initialized() and (dist.get_world_size() > 1 or forced())):
             return
         world = dist.get_world_size()
         for bucket in self.buckets:

@@ -58,3 +58,38 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02     # whole-job aggregate: both ranks' views / the slowest rank's time
     assert d["cpu_baseline"] is None                  # rank 0 at N = 1 only
     assert d["stage2_path"]["n_gpus"] == 2 and d["stage2_path"]["iters_per_s"] > 0
+
+
+def test_plain_command_with_gpus_2_starts_two_ranks():
+    """The driver's command shape -- `python bench.py --gpus 2 ...`, no torchrun around it -- becomes two ranks by itself (re-exec under
+    torch.distributed.run with a 127.0.0.1 rendezvous).  On this 1-GPU box both ranks share device 0 and talk over gloo."""
+    env = dict(os.environ, GPSGS_BENCH_SINGLE_DEVICE="1", GPSGS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--res", "256", "--gaussians", "30000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["stage2_path"]["n_gpus"] == 2 and d["stage2_path"]["allreduce"].startswith("gloo, world 2")
+
+
+def test_gpus_2_on_a_one_gpu_node_fails_loudly():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPSGS_BENCH_SINGLE_DEVICE")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "exposes 1 GPU" in r.stderr, r.stderr[-1000:]
+
+
+def test_world_1_through_rccl():
+    """GPSGS_DIST_FORCE=1: one rank, but the process group IS initialised with backend nccl (= RCCL) and the stage-2 exchange step (mean
+    all-reduce of 5,144,408 gradients, one bucket) IS issued -- RCCL's communicator set-up and its all-reduce kernel run on the MI355X."""
+    env = dict(os.environ, GPSGS_DIST_FORCE="1", GPSGS_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--res", "256", "--gaussians", "30000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["stage2_path"]["allreduce"].startswith("nccl, world 1 (forced"), d["stage2_path"]

@@ -84,13 +84,22 @@ HOOK = textwrap.dedent('''
 ''')
 
 
-def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path):
+@pytest.mark.parametrize("form", ["checkout", "staged-bytecode"])
+def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path, form):
+    ref = REF
+    if form == "staged-bytecode":     # what the GPU box has: oracle/stage_ref.py's build of the reference (sourceless .pyc + YAML)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        try:
+            import stage_ref
+        finally:
+            sys.path.pop(0)
+        ref = stage_ref.stage(REF, str(tmp_path / "GPS-Gaussian"), quiet=True)
     hook = tmp_path / "hook.py"
     hook.write_text(HOOK)
     out = tmp_path / "result.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", LAUNCH_TEST_OUT=str(out))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(ROOT, "tools", "launch_stage2.py"), "--reference", REF, "--backend", "gloo", "--steps", "6", "--exp-root", str(tmp_path / "experiments"),
+           os.path.join(ROOT, "tools", "launch_stage2.py"), "--reference", ref, "--backend", "gloo", "--steps", "6", "--exp-root", str(tmp_path / "experiments"),
            "--hook", str(hook), "stage1_ckpt", "None", "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", "1000"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]

@@ -37,43 +37,9 @@ from pathlib import Path
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-
-
-def _install_shims():
-    """Stand-ins for packages the MI355X image lacks; never shadows a real installation."""
-    for name in ("yacs", "cv2"):
-        try:
-            importlib.import_module(name)
-        except ImportError:
-            p = os.path.join(HERE, "shims")
-            if p not in sys.path:
-                sys.path.append(p)  # behind everything else
-    try:
-        importlib.import_module("torch.utils.tensorboard")
-    except Exception:  # noqa: BLE001  (ImportError from the missing `tensorboard` package)
-        m = types.ModuleType("torch.utils.tensorboard")
-
-        class SummaryWriter:
-            """Scalars as JSON lines (events.jsonl) instead of TensorBoard event files."""
-
-            def __init__(self, log_dir=None, **_):
-                self.f = None
-                if log_dir:
-                    Path(log_dir).mkdir(parents=True, exist_ok=True)
-                    self.f = open(os.path.join(log_dir, "events.jsonl"), "a")
-
-            def add_scalar(self, tag, value, step=None, **_):
-                if self.f:
-                    self.f.write(json.dumps({"tag": tag, "value": float(value), "step": None if step is None else int(step)}) + "\n")
-                    self.f.flush()
-
-            def close(self):
-                if self.f:
-                    self.f.close()
-                    self.f = None
-
-        m.SummaryWriter = SummaryWriter
-        sys.modules["torch.utils.tensorboard"] = m
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+import refenv  # noqa: E402  (shims, reference discovery: shared with tools/run_reference.py)
 
 
 class _SilentLogger:
@@ -99,10 +65,58 @@ class _SilentLogger:
         pass
 
 
+def _install_timing(TS, trainer, torch):
+    """hipEvent brackets around the calls of the reference's own training iteration (train_stage2.py:57-97), by wrapping the names its
+    loop resolves at call time: `self.model(...)`, module-level `pts2render`, `l1_loss`, `ssim`, `self.scaler.scale(loss)` ->
+    `.backward()`, `self.scaler.step`.  Returns a function producing {span: [ms per iteration ...], "iter_ms": [...]}."""
+    import time
+    spans, stamps = {}, []
+
+    def bracket(name, fn):
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            spans.setdefault(name, []).append((e0, e1))
+            return out
+        return timed
+
+    trainer.model.forward = bracket("network_forward", trainer.model.forward)
+    TS.pts2render = bracket("pts2render", TS.pts2render)
+    TS.l1_loss = bracket("loss_l1", TS.l1_loss)
+    TS.ssim = bracket("loss_ssim", TS.ssim)
+    real_scale = trainer.scaler.scale
+
+    def scale(loss):
+        out = real_scale(loss)
+        out.backward = bracket("backward", out.backward)
+        return out
+    trainer.scaler.scale = scale
+    real_step = trainer.scaler.step
+
+    def step(opt, *a, **k):
+        stamps.append(time.perf_counter())
+        return bracket("optimizer_step", real_step)(opt, *a, **k)
+    trainer.scaler.step = step
+
+    def result():
+        torch.cuda.synchronize()
+        out = {k: [round(a.elapsed_time(b), 3) for a, b in v] for k, v in spans.items()}
+        out["iter_ms"] = [round((stamps[i] - stamps[i - 1]) * 1e3, 3) for i in range(1, len(stamps))]
+        return out
+    return result
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
-    ap.add_argument("--reference", required=True, help="checkout of aipixel/GPS-Gaussian (unmodified)")
-    ap.add_argument("--config", default="config/stage2.yaml", help="relative to --reference")
+    ap.add_argument("--reference", default=None, help="checkout of aipixel/GPS-Gaussian (unmodified); default: /root/reference, else the bytecode build "
+                                                      "oracle/stage_ref.py leaves in oracle/_ref/GPS-Gaussian")
+    ap.add_argument("--config", default="config/stage2.yaml", help="relative to the working directory (--workdir, default: the reference)")
+    ap.add_argument("--workdir", default=None, help="cwd for the reference's cwd-relative paths: a scratch directory made by tools/refenv.make_workdir "
+                                                    "(links to the reference + its own config/stage2.yaml); default: the reference itself")
+    ap.add_argument("--timing", default=None, help="write per-iteration hipEvent timings of the reference's own calls (model, pts2render, l1_loss + ssim, "
+                                                   "backward, optimizer) as JSON to this file (rank 0)")
     ap.add_argument("--steps", type=int, default=None, help="override cfg.num_steps")
     ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo")
     ap.add_argument("--exp-root", default=None, help="where experiments/<name>/ goes (default: the reference's cwd-relative 'experiments')")
@@ -120,7 +134,9 @@ def main(argv=None):
     from gps_gaussian_amd import DROPIN_DIR
     from gps_gaussian_amd import dist as D
 
-    ref = os.path.abspath(args.reference)
+    ref = refenv.reference_dir(args.reference)
+    if ref is None:
+        raise SystemExit("launch_stage2: no reference checkout (looked at --reference, $GPSGS_REFERENCE, /root/reference, oracle/_ref/GPS-Gaussian)")
     rank, local_rank, world = D.env_rank()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
@@ -128,10 +144,9 @@ def main(argv=None):
     dev = torch.device("cuda", local_rank) if use_cuda else None
     D.init(backend=args.backend, device=dev)  # no-op at world size 1
 
-    _install_shims()
-    sys.path.insert(0, ref)
-    sys.path.insert(0, DROPIN_DIR)  # `import diff_gaussian_rasterization` / `import corr_sampler` -> the MI355X kernels
-    os.chdir(ref)                   # the reference uses cwd-relative paths ("config/stage2.yaml", file_backup's 'core', 'lib', ...)
+    refenv.activate(ref)            # shims if needed; DROPIN_DIR (`import diff_gaussian_rasterization` / `import corr_sampler` -> the MI355X
+    assert sys.path[0] == DROPIN_DIR  # kernels) ahead of the reference on sys.path
+    os.chdir(args.workdir or ref)   # the reference uses cwd-relative paths ("config/stage2.yaml", file_backup's 'core', 'lib', ...)
 
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING,
                         format="%(asctime)s %(levelname)-8s [rank " + str(rank) + " %(filename)s:%(lineno)d] %(message)s")
@@ -155,7 +170,7 @@ def main(argv=None):
     if rank == 0:
         for path in (cfg.record.ckpt_path, cfg.record.show_path, cfg.record.logs_path, cfg.record.file_path):
             Path(path).mkdir(exist_ok=True, parents=True)
-        TS.file_backup(cfg.record.file_path, cfg, train_script="train_stage2.py")
+        TS.file_backup(cfg.record.file_path, cfg, train_script=os.path.basename(TS.__file__))  # train_stage2.py:204
     D.barrier(local_rank if use_cuda else None)
     TS.cfg = cfg  # Trainer's methods read this module global (train_stage2.py:44,76,101,123)
 
@@ -204,11 +219,15 @@ def main(argv=None):
         return real_unscale(optimizer)
 
     trainer.scaler.unscale_ = unscale_after_allreduce
+    timing = _install_timing(TS, trainer, torch) if (args.timing and rank == 0 and use_cuda) else None
     if rank != 0:
         trainer.save_ckpt = lambda *a, **k: None
         trainer.run_eval = lambda *a, **k: None
     trainer.train()
     D.barrier(local_rank if use_cuda else None)
+    if timing is not None:
+        with open(args.timing, "w") as f:
+            json.dump(timing(), f)
     if rank == 0:
         print(json.dumps({"launcher": "launch_stage2", "world_size": world, "steps": int(trainer.total_steps), "exchange": "mean all-reduce of %d gradients in %d bucket(s)"
                           % (sum(p.numel() for p in reducer.params), len(reducer.buckets)), "backend": dist.get_backend() if dist.is_initialized() else None}))

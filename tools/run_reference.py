@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Run the reference's OWN scripts, unmodified, on the MI355X drop-in and time them (BASELINE configs 3 and 4; harness, not product).
+
+    python tools/run_reference.py interp [--samples 2] [--views 5] [--res 1024]      test_view_interp.py   (config 3)
+    python tools/run_reference.py train  [--steps 12] [--batch 2] [--res 1024]       train_stage2.py       (config 4, one process)
+
+The reference is found by tools/refenv.reference_dir(): /root/reference in the build container, the bytecode build in the git-ignored
+oracle/_ref/GPS-Gaussian (oracle/stage_ref.py) on the GPU box.  The script is executed as `__main__` by runpy -- the same code object
+`python test_view_interp.py ...` would run -- from a scratch working directory (tools/refenv.make_workdir) with
+gps-gaussian_amd/dropin ahead of the reference on sys.path.  What the harness supplies, and nothing else:
+  * a synthetic data set in the loader's on-disk layout (tools/make_synthetic_dataset.py) -- the reference's real
+    `StereoHumanDataset` reads, rectifies and collates it;
+  * randomly initialised network weights saved as the checkpoint `--ckpt_path` asks for (no pretrained weights offline);
+  * stand-ins for yacs / cv2 / tensorboard when the packages are missing (tools/shims);
+  * clocks: the time of every cv2.imwrite of a rendered view (interp), of every optimizer step (train), and -- in a second, INSTRUMENTED
+    pass that imports the script as a module -- hipEvent brackets around the reference's `model(...)`, `pts2render(...)` and loss calls.
+Prints one JSON line.
+"""
+import argparse
+import json
+import os
+import runpy
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import refenv  # noqa: E402
+
+
+def _dataset(work, res, n_train, n_val, fill):
+    import make_synthetic_dataset as M
+    root = os.path.join(work, "data_%d" % res)
+    if not os.path.isdir(os.path.join(root, "val", "img")):
+        M.make_dataset(root, res=res, n_train=n_train, n_val=n_val, fill=fill, quiet=True)
+    return root
+
+
+def _cfg(work, yaml_name="stage2.yaml"):
+    from config.stereo_human_config import ConfigStereoHuman
+    c = ConfigStereoHuman()
+    c.load(os.path.join(work, "config", yaml_name))
+    return c.get_cfg()
+
+
+class _Clock:
+    """hipEvent brackets around a callable; totals read after a synchronize."""
+
+    def __init__(self, torch):
+        self.torch, self.spans = torch, {}
+
+    def wrap(self, name, fn):
+        torch = self.torch
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.spans.setdefault(name, []).append((e0, e1))
+            return out
+        return timed
+
+    def totals(self, skip=0):
+        self.torch.cuda.synchronize()
+        return {k: (round(sum(a.elapsed_time(b) for a, b in v[skip:]) / max(1, len(v[skip:])), 3), len(v[skip:])) for k, v in self.spans.items()}
+
+
+def interp(args):
+    import numpy as np
+    import torch
+
+    ref = refenv.reference_dir(args.reference)
+    if ref is None:
+        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+    refenv.activate(ref)
+    work = os.path.abspath(args.work)
+    data_root = _dataset(work, args.res, 0, args.samples, args.fill)
+    refenv.make_workdir(ref, work, {"dataset": {"src_res": args.res}})
+    os.chdir(work)
+    cfg = _cfg(work)
+    # randomly initialised weights in the checkpoint format the script loads (test_view_interp.py:61-66)
+    from lib.network import RtStereoHumanModel
+    torch.manual_seed(1314)
+    ckpt = os.path.join(work, "random_init_stage2.pth")
+    torch.save({"network": RtStereoHumanModel(cfg, with_gs_render=True).state_dict()}, ckpt)
+
+    import cv2
+    stamps = []
+    real_imwrite = cv2.imwrite
+
+    def imwrite(path, img):
+        torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+        return real_imwrite(path, img) if args.write_images else True
+    cv2.imwrite = imwrite
+
+    test_root = os.path.join(data_root, "val")
+    argv = ["test_view_interp", "--test_data_root", test_root, "--ckpt_path", ckpt, "--novel_view_nums", str(args.views)]
+    out = {"mode": "interp", "reference": ref, "script": os.path.basename(refenv.script(ref, "test_view_interp")), "res": args.res,
+           "render": "%dx%d" % (2 * args.res, 2 * args.res), "samples": args.samples, "views_per_sample": args.views}
+    # ---- pass 1: the script itself, as __main__ ----------------------------------------------------------------------------------
+    for rep in range(2):  # the second run is the measured one (first: MIOpen / allocator / capacity warm-up)
+        del stamps[:]
+        old = sys.argv
+        sys.argv = argv
+        t0 = time.perf_counter()
+        try:
+            runpy.run_path(refenv.script(ref, "test_view_interp"), run_name="__main__")
+        finally:
+            sys.argv = old
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    n = len(stamps)
+    assert n == args.samples * args.views, (n, args.samples, args.views)
+    out["script_run"] = {"views": n, "wall_s": round(wall, 3), "views_per_s_end_to_end": round(n / wall, 3),
+                         "note": "whole script: model construction + checkpoint load + per-sample loader (disk, rectification on the host) + "
+                                 "per-view network + render + .cpu(); the JPEG write itself is %s" % ("included" if args.write_images else "skipped")}
+    # views inside one sample follow each other without the loader in between
+    gaps = [stamps[i] - stamps[i - 1] for i in range(1, n) if i % args.views]
+    if gaps:
+        out["script_run"]["views_per_s_within_sample"] = round(1.0 / float(np.median(gaps)), 3)
+
+    # ---- pass 2: instrumented (module import; same classes, hipEvents around the reference's own calls) ----------------------------
+    import importlib
+    TVI = importlib.import_module("test_view_interp")
+    import lib.GaussianRender as GR
+    import gaussian_renderer as GRR
+    import diff_gaussian_rasterization as DGR
+    import gps_gaussian_amd.rasterizer as RZ
+    assert DGR.GaussianRasterizer is RZ.GaussianRasterizer and GRR.GaussianRasterizer is RZ.GaussianRasterizer
+    clk = _Clock(torch)
+    cfg.defrost()
+    cfg.batch_size = 1
+    cfg.dataset.test_data_root = test_root
+    cfg.dataset.use_processed_data = False
+    cfg.restore_ckpt = ckpt
+    cfg.test_out_path = os.path.join(work, "interp_out")
+    os.makedirs(cfg.test_out_path, exist_ok=True)
+    cfg.freeze()
+    r = TVI.StereoHumanRender(cfg, phase="test")
+    r.model.forward = clk.wrap("network", r.model.forward)
+    TVI.pts2render = clk.wrap("pts2render", TVI.pts2render)
+    GR.render = clk.wrap("render", GR.render)
+    Ps = []
+    real_fwd = RZ._forward_impl
+
+    def spy(ctx, means3D, *a, **k):
+        Ps.append(int(means3D.shape[0]))
+        return real_fwd(ctx, means3D, *a, **k)
+    RZ._forward_impl = spy
+    del stamps[:]
+    r.infer_static(view_select=[0, 1], novel_view_nums=args.views)
+    tot = clk.totals(skip=1)
+    RZ._forward_impl = real_fwd
+    out["gpu_ms_per_view"] = {k: v[0] for k, v in tot.items()}
+    out["gpu_ms_per_view"]["pack_inside_pts2render"] = round(tot["pts2render"][0] - tot["render"][0], 3)
+    out["gaussians_per_view"] = {"mean": int(np.mean(Ps)), "min": int(min(Ps)), "max": int(max(Ps))}
+    gpu_ms = tot["network"][0] + tot["pts2render"][0]
+    out["views_per_s_gpu_side"] = round(1e3 / gpu_ms, 2)
+    out["raster_share_of_gpu_time"] = round(tot["render"][0] / gpu_ms, 4)
+    img = None
+    try:
+        from PIL import Image
+        files = sorted(os.listdir(cfg.test_out_path))
+        if files and args.write_images:
+            img = np.asarray(Image.open(os.path.join(cfg.test_out_path, files[0])))
+            out["first_image"] = {"file": files[0], "shape": list(img.shape), "nonblack_fraction": round(float((img.max(-1) > 8).mean()), 4)}
+    except Exception as e:  # noqa: BLE001
+        out["first_image"] = {"error": repr(e)[:200]}
+    print(json.dumps(out))
+    return out
+
+
+def train(args):
+    """train_stage2.py as __main__, one process, the reference's real data set class on the synthetic set, real networks, random init."""
+    import numpy as np
+    import torch
+
+    ref = refenv.reference_dir(args.reference)
+    if ref is None:
+        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+    refenv.activate(ref)
+    work = os.path.abspath(args.work)
+    data_root = _dataset(work, args.res, args.train_samples, 2, args.fill)
+    refenv.make_workdir(ref, work, {"stage1_ckpt": "None", "batch_size": args.batch, "num_steps": args.steps, "dataset": {"src_res": args.res, "data_root": data_root},
+                                    "record": {"loss_freq": max(2, args.steps // 2), "eval_freq": args.eval_freq or 10 * args.steps}})
+    os.chdir(work)
+    stamps = []
+    real_step = torch.optim.AdamW.step
+
+    def step(self, *a, **k):
+        stamps.append(time.perf_counter())
+        return real_step(self, *a, **k)
+    torch.optim.AdamW.step = step
+    t0 = time.perf_counter()
+    runpy.run_path(refenv.script(ref, "train_stage2"), run_name="__main__")
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    torch.optim.AdamW.step = real_step
+    n = len(stamps)
+    tail = stamps[n // 2:]
+    exp = os.path.join(work, "experiments")
+    ck = [os.path.join(dp, f) for dp, _, fs in os.walk(exp) for f in fs if f.endswith("_final.pth")]
+    out = {"mode": "train", "reference": ref, "script": os.path.basename(refenv.script(ref, "train_stage2")), "res": args.res, "batch": args.batch,
+           "optimizer_steps": n, "wall_s": round(wall, 2),
+           "iters_per_s_second_half": round((len(tail) - 1) / (tail[-1] - tail[0]), 3) if len(tail) > 1 else None,
+           "final_checkpoint_written": bool(ck)}
+    if ck:
+        sd = torch.load(ck[-1], map_location="cpu")
+        out["finite_weights"] = bool(all(torch.isfinite(v).all() for v in sd["network"].values() if v.is_floating_point()))
+        out["total_steps"] = int(sd["total_steps"])
+    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("mode", choices=("interp", "train"))
+    ap.add_argument("--reference", default=None)
+    ap.add_argument("--work", default=os.environ.get("GPSGS_REF_WORK", "/tmp/gpsgs_ref_work"))
+    ap.add_argument("--res", type=int, default=1024, help="source resolution (dataset.src_res); the render is 2x that (use_hr_img)")
+    ap.add_argument("--fill", type=float, default=0.28, help="fraction of a source image the synthetic human covers (~P / (2 res^2))")
+    ap.add_argument("--samples", type=int, default=2)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--train-samples", type=int, default=4)
+    ap.add_argument("--eval-freq", type=int, default=0)
+    ap.add_argument("--write-images", action="store_true")
+    args = ap.parse_args()
+    return interp(args) if args.mode == "interp" else train(args)
+
+
+if __name__ == "__main__":
+    main()
