@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
-    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_backward", "gsr_copy_header_async", "gsr_read_header",
+    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_selftest", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
     "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
@@ -28,7 +28,13 @@ class GsrStrided(C.Structure):
 
 class GsrHeader(C.Structure):
     _fields_ = [("num_rendered", C.c_uint64), ("overflow", C.c_uint32), ("max_tile_count", C.c_uint32),
-                ("num_busy_wgs", C.c_uint32), ("num_slots", C.c_uint32), ("reserved", C.c_uint32 * 10)]
+                ("num_busy_wgs", C.c_uint32), ("num_slots", C.c_uint32), ("num_points", C.c_uint32), ("row_overflow", C.c_uint32),
+                ("reserved", C.c_uint32 * 8)]
+
+
+class GsrViewExt(C.Structure):
+    """Optional extras of one view (include/gpsgs.h): device pointer to the {begin, end} row range, work-order hint."""
+    _fields_ = [("row_range", C.c_void_p), ("order_hint", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 _lib = None
@@ -57,9 +63,13 @@ def lib():
     l.gsr_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, sz, i64, u32, vp]
     l.gsr_forward_notify.restype = i32
     l.gsr_forward_notify.argtypes = l.gsr_forward.argtypes + [vp, u32]
+    l.gsr_forward_ex.restype = i32
+    l.gsr_forward_ex.argtypes = l.gsr_forward_notify.argtypes + [C.POINTER(GsrViewExt)]
     l.gsr_backward.restype = i32
     l.gsr_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                vp, vp, sz, i64, u32, vp]
+    l.gsr_backward_ex.restype = i32
+    l.gsr_backward_ex.argtypes = l.gsr_backward.argtypes + [C.POINTER(GsrViewExt)]
     l.gsr_copy_header_async.restype = i32
     l.gsr_copy_header_async.argtypes = [vp, vp, vp]
     l.gsr_read_header.restype = i32
@@ -106,7 +116,7 @@ def lib():
     l.cu_upsample_backward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.cu_upsample_scratch_bytes.restype = sz
     l.cu_upsample_scratch_bytes.argtypes = [i32, i32, i32, i32]
-    if l.gpsgs_abi_version() != 1:
+    if l.gpsgs_abi_version() != 2:
         raise ImportError("gps_gaussian_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = l
     return l

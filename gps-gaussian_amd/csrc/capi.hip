@@ -1,6 +1,9 @@
 // capi.hip -- extern "C" entry points of libgpsgs_hip.so (declared in include/gpsgs.h).
 // Pure enqueue: no allocation, no host synchronisation (except in the explicit *_read_header helper and under
 // GSR_FLAG_DEBUG), so a forward+backward pair can be captured into a hipGraph.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "gsr_common.h"
 
 namespace {
@@ -8,11 +11,26 @@ namespace {
 inline uint8_t *at(void *ws, size_t off) { return reinterpret_cast<uint8_t *>(ws) + off; }
 inline const uint8_t *at(const void *ws, size_t off) { return reinterpret_cast<const uint8_t *>(ws) + off; }
 
+// GPSGS_TRACE=1 (environment): every rasteriser stage announces itself on stderr before its launch and is synchronised after it --
+// a device fault then names the stage that was running (a GPU memory fault aborts the process; there is nothing to return).
+inline bool trace_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GPSGS_TRACE");
+        v = (e && *e && *e != '0') ? 1 : 0;
+    }
+    return v == 1;
+}
+inline void trace(const char *what, int P, int W, int H, long long cap, unsigned flags) {
+    if (trace_on()) { fprintf(stderr, "[gpsgs] %s P=%d %dx%d cap=%lld flags=0x%x ...", what, P, W, H, cap, flags); fflush(stderr); }
+}
+
 inline int check(hipStream_t s, unsigned flags) {
     if (hipGetLastError() != hipSuccess) return GPSGS_E_LAUNCH;
-    if (flags & GSR_FLAG_DEBUG) {
+    if ((flags & GSR_FLAG_DEBUG) || trace_on()) {
         if (hipStreamSynchronize(s) != hipSuccess) return GPSGS_E_LAUNCH;
         if (hipGetLastError() != hipSuccess) return GPSGS_E_LAUNCH;
+        if (trace_on()) { fprintf(stderr, " ok\n"); fflush(stderr); }
     }
     return GPSGS_OK;
 }
@@ -80,11 +98,13 @@ extern "C" size_t gsr_workspace_bytes_forward_only(int P, int width, int height,
     return gsr_layout(P, width, height, instance_capacity).total_fwd;
 }
 
-extern "C" int gsr_forward_notify(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
-                                  const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
-                                  const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
-                                  void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream,
-                                  void *host_header_out, uint32_t notify_seq) {
+extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                              const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                              const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                              void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream,
+                              void *host_header_out, uint32_t notify_seq, const GsrViewExt *ext) {
+    const uint32_t *row_range = ext ? ext->row_range : nullptr;
+    const uint32_t order_hint = ext ? ext->order_hint : 0u;
     if (P < 0 || width <= 0 || height <= 0 || instance_capacity < 0 || instance_capacity > 0x7fffffffLL) return GPSGS_E_INVALID;
     if (width > 65535 * GSR_TILE || height > 65535 * GSR_TILE) return GPSGS_E_INVALID;
     if (!out_color || !workspace) return GPSGS_E_INVALID;
@@ -108,7 +128,6 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     uint32_t *bin_cursor = reinterpret_cast<uint32_t *>(at(workspace, L.bin_cursor));
     uint32_t *wg_order = reinterpret_cast<uint32_t *>(at(workspace, L.wg_order));
     uint4 *scan_part = reinterpret_cast<uint4 *>(at(workspace, L.scan_part));
-    uint32_t *order_hint = reinterpret_cast<uint32_t *>(at(workspace, L.order_hint));
     GsrSplat *splats = reinterpret_cast<GsrSplat *>(at(workspace, L.splats));
     uint32_t *hitmask = reinterpret_cast<uint32_t *>(at(workspace, L.hitmask));
     uint32_t *wg_tab = reinterpret_cast<uint32_t *>(at(workspace, L.wg_tab));
@@ -129,6 +148,7 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     q.means3D = means3D; q.colors = colors; q.opacities = opacities; q.scales = scales; q.rotations = rotations;
     q.scale_modifier = scale_modifier; q.tanfovx = tanfovx; q.tanfovy = tanfovy;
     q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity;
+    q.row_range = row_range;
     // a workspace that includes the backward tail gets the per-Gaussian slot prefix and cleared record flags from the forward
     const bool training = workspace_bytes >= L.total;
     q.goff = training ? reinterpret_cast<uint32_t *>(at(workspace, L.goff)) : nullptr;
@@ -138,27 +158,32 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
 
     int rc;
     {
+        trace("preprocess", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_PREPROCESS, s);
         gsr_launch_preprocess(q, splats, hitmask, wg_tab, bin_count, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
+        trace("scan", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_SCAN, s);
         gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, L.bx, L.by, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
                         (flags & GSR_FLAG_NO_LARGE_SORT) != 0, order_hint, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
+        trace("scatter", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, order_hint, s);
+        gsr_launch_scatter(P, row_range, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
+        trace("sort", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_SORT, s);
         gsr_launch_sort(L.NB, bin_offset, wg_order, keys, point_list, hdr, (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
+        trace("composite_fwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
         if (flags & GSR_FLAG_COMPOSITE_TILES)
             gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, training, s);
@@ -168,20 +193,29 @@ extern "C" int gsr_forward_notify(int P, int width, int height, const float *mea
     return check(s, flags);
 }
 
+extern "C" int gsr_forward_notify(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                                  const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                                  const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                                  void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream,
+                                  void *host_header_out, uint32_t notify_seq) {
+    return gsr_forward_ex(P, width, height, means3D, colors, opacities, scales, rotations, scale_modifier, tanfovx, tanfovy, viewmatrix, projmatrix,
+                          bg, out_color, radii, workspace, workspace_bytes, instance_capacity, flags, stream, host_header_out, notify_seq, nullptr);
+}
+
 extern "C" int gsr_forward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
                            const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
                            const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
                            void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream) {
-    return gsr_forward_notify(P, width, height, means3D, colors, opacities, scales, rotations, scale_modifier, tanfovx, tanfovy, viewmatrix,
-                              projmatrix, bg, out_color, radii, workspace, workspace_bytes, instance_capacity, flags, stream, nullptr, 0u);
+    return gsr_forward_ex(P, width, height, means3D, colors, opacities, scales, rotations, scale_modifier, tanfovx, tanfovy, viewmatrix, projmatrix,
+                          bg, out_color, radii, workspace, workspace_bytes, instance_capacity, flags, stream, nullptr, 0u, nullptr);
 }
 
-extern "C" int gsr_backward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
-                            const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
-                            const float *viewmatrix, const float *projmatrix, const float *bg, const int *radii,
-                            const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
-                            float *dL_dscales, float *dL_drotations, void *workspace, size_t workspace_bytes,
-                            int64_t instance_capacity, unsigned flags, void *stream) {
+extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                               const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                               const float *viewmatrix, const float *projmatrix, const float *bg, const int *radii,
+                               const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                               float *dL_dscales, float *dL_drotations, void *workspace, size_t workspace_bytes,
+                               int64_t instance_capacity, unsigned flags, void *stream, const GsrViewExt *ext) {
     (void)colors; (void)opacities;  // already folded into the splat records of the workspace
     if (P < 0 || width <= 0 || height <= 0 || instance_capacity < 0) return GPSGS_E_INVALID;
     if (P == 0) return GPSGS_OK;
@@ -207,6 +241,7 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     // goff / gscan_part / cleared inst_valid were produced by the matching gsr_forward (training workspace)
     int rc;
     {
+        trace("composite_bwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_COMPOSITE_BWD, s);
         // must be the same family as the forward that filled the workspace: the two designs round the exponent differently, and the
         // backward has to repeat the forward's per-pixel decisions
@@ -223,11 +258,24 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
     b.view = viewmatrix; b.proj = projmatrix; b.radii = radii;
     b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
+    b.row_range = ext ? ext->row_range : nullptr;
     {
+        trace("preprocess_bwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);
         gsr_launch_preprocess_bwd(b, splats, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
     }
     return check(s, flags);
+}
+
+extern "C" int gsr_backward(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                            const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                            const float *viewmatrix, const float *projmatrix, const float *bg, const int *radii,
+                            const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity,
+                            float *dL_dscales, float *dL_drotations, void *workspace, size_t workspace_bytes,
+                            int64_t instance_capacity, unsigned flags, void *stream) {
+    return gsr_backward_ex(P, width, height, means3D, colors, opacities, scales, rotations, scale_modifier, tanfovx, tanfovy, viewmatrix, projmatrix, bg,
+                           radii, dL_dpix, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, workspace, workspace_bytes,
+                           instance_capacity, flags, stream, nullptr);
 }
 
 extern "C" int gsr_selftest(float *out4_device, void *stream) {

@@ -56,13 +56,13 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum /*[1
     return woff + x - v;
 }
 
-// Work classes of a bin in the compositing / sort order, by the length of its list relative to the longest list the previous forward
-// on this workspace saw (hint): class 0 = more than 1/2 of it, 1 = more than 1/4, 2 = any other busy bin, 3 = idle.  The classes are
+// Work classes of a bin in the compositing / sort order, by the length of its list relative to the longest list an earlier, similar
+// view produced (hint: GsrViewExt.order_hint, a kernel argument; 0 = unknown = every busy bin in class 0 = plain patch order): class 0 = more than 1/2 of it, 1 = more than 1/4, 2 = any other busy bin, 3 = idle.  The classes are
 // dispatched in that order: a bin is ONE wave's sequential job and a SIMD gets only ~5 of them per kernel, so a 900-entry list that
 // starts late is what the other SIMDs end up waiting for (longest-processing-time-first, coarsely).  Two packed counters:
 // w0 = class 0 | class 1 << 16, w1 = class 2 | idle << 16 (each count <= 1024 per scan block).
 // The order is a performance hint only (every bin is handled exactly once whatever its position), so the threshold may be anything:
-// it comes from a word in the workspace that k_scatter refreshes after the scan (uninitialised the first time: harmless).
+// the caller passes what the header of an earlier forward reported (max_tile_count).
 __device__ __forceinline__ int work_class(int wb, uint32_t wc, uint32_t hint) {
     return wb < 0 ? -1 : (wc > (hint >> 1) ? 0 : (wc > (hint >> 2) ? 1 : (wc > 0u ? 2 : 3)));
 }
@@ -72,11 +72,10 @@ __device__ __forceinline__ uint32_t class_w1(int cls) { return cls == 2 ? 1u : (
 // phase A: per block of 1024 indices -> part[2 blk] = {sum of counts (bins in image order), w0 of the block's indices in WORK order
 // (tiled_bin), max count, -}, part[2 blk + 1].x = their w1
 __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part, int NB, int bx, int by,
-                                               const uint32_t *__restrict__ order_hint) {
+                                               uint32_t hint) {
     __shared__ uint32_t red[4][SB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x * SB + tid;
-    const uint32_t hint = *order_hint;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
     const int wb = tiled_bin((uint32_t)b, bx, by);
     const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] : 0u;
@@ -113,11 +112,10 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
                                                uint32_t *__restrict__ wg_order, int NB, int bx, int by, int nblocks, int64_t cap,
                                                GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
                                                uint32_t *__restrict__ host_hdr, uint32_t host_seq, int no_large_sort,
-                                               const uint32_t *__restrict__ order_hint) {
+                                               uint32_t hint) {
     __shared__ uint32_t wsum[SB / 64];
     __shared__ uint4 sp[FUSED ? GSR_SCAN_FUSE_MAX : 1];
     __shared__ uint32_t sp_idle[FUSED ? GSR_SCAN_FUSE_MAX : 1];
-    const uint32_t hint = *order_hint;  // the same word for every block of this launch: it is only rewritten by k_scatter
     const int tid = threadIdx.x;
     const int b = blockIdx.x * SB + tid;
     const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         hdr->num_rendered = tot_sum;
         // a list longer than 1024 entries while the caller skipped the large-list sort launch is reported like an overflow:
         // every later kernel exits, the caller sees max_tile_count > 1024 and calls again with that launch
-        const bool ovf_b = (int64_t)tot_sum > cap || (int64_t)tot_slots > cap || (no_large_sort && tot_max > 1024u);
+        const bool ovf_b = (int64_t)tot_sum > cap || (int64_t)tot_slots > cap || (no_large_sort && tot_max > 1024u) || hdr->row_overflow != 0u;
         hdr->overflow = ovf_b ? 1u : 0u;
         hdr->max_tile_count = tot_max;
         hdr->num_busy_wgs = tot_busy;
@@ -199,7 +197,7 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
             // capacity while scatter / sort / compositing are still running (no copy engine, no event in the stream)
             const uint32_t ovf = ovf_b ? 1u : 0u;
             volatile uint32_t *h = host_hdr;
-            h[0] = (uint32_t)tot_sum; h[1] = (uint32_t)(tot_sum >> 32); h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = 0u;
+            h[0] = (uint32_t)tot_sum; h[1] = (uint32_t)(tot_sum >> 32); h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = hdr->num_points;
             __threadfence_system();
             __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this word
         }
@@ -223,16 +221,16 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     }
 }
 
-__global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
+__global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, const uint32_t *__restrict__ row_range, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
                                                             const uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
                                                             const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
-                                                            const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid,
-                                                            uint32_t *__restrict__ order_hint) {
+                                                            const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid) {
     if (hdr->overflow) return;
-    // the longest list of THIS forward becomes the next forward's threshold for "long" lists (k_scan_a/b work_class); written here,
-    // after every block of the scan has read the old value (stream order)
-    if (blockIdx.x == 0 && threadIdx.x == 0) *order_hint = hdr->max_tile_count;
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
+    {
+        uint32_t row0;
+        gsr_view_rows(row_range, P, row0, P);  // with a row range P was only the capacity: records behind the view's last Gaussian were never written
+    }
     uint32_t lo = 0, hi = 0, mask = 0;
     uint64_t key = 0;
     GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
@@ -460,7 +458,7 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
-                     const uint32_t *order_hint, hipStream_t s) {
+                     uint32_t order_hint, hipStream_t s) {
     const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB: ragged patches at the grid edge)
     const int nblocks = ((NT > NB ? NT : NB) + SB - 1) / SB;
     if (nblocks <= GSR_SCAN_FUSE_MAX) {
@@ -473,11 +471,11 @@ void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *
                        gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0, order_hint);
 }
 
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, uint32_t *order_hint, hipStream_t s) {
+void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr,
-                       goff, gpart, inst_valid, order_hint);
+    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, row_range, bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr,
+                       goff, gpart, inst_valid);
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,

@@ -65,7 +65,7 @@ struct __attribute__((aligned(32))) GsrGradAcc {
 static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte sector");
 
 struct GsrLayout {
-    size_t header, bin_count, bin_offset, bin_cursor, wg_order, order_hint, scan_part, splats, hitmask, wg_tab, keys, point_list, final_T, n_contrib;
+    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, hitmask, wg_tab, keys, point_list, final_T, n_contrib;
     size_t total_fwd;  // bytes a forward-only workspace needs
     size_t goff, gscan_part, inst_valid, inst_dop, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
@@ -100,7 +100,6 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     L.bin_offset = o; o = gsr_align_up(o + (t + 1) * 4);
     L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
-    L.order_hint = o; o = gsr_align_up(o + 4);  // longest list of the previous forward on this workspace (never cleared: a hint)
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
     L.hitmask = o;    o = gsr_align_up(o + p * 4);
     L.wg_tab = o;     o = gsr_align_up(o + ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
@@ -310,15 +309,16 @@ struct GsrFwdParams {
     int *radii;
     int64_t cap;
     uint32_t *goff, *gpart;  // backward tail of the workspace (NULL for a forward-only workspace)
+    const uint32_t *row_range;  // device {begin, end} or NULL: the view's Gaussians are rows [begin, end) of the batch-wide arrays, P = capacity
 };
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
                            hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
-                     const uint32_t *order_hint, hipStream_t s);
-void gsr_launch_scatter(int P, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, uint32_t *order_hint, hipStream_t s);
+                     uint32_t order_hint, hipStream_t s);
+void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
+                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s);
 void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
@@ -351,6 +351,21 @@ struct GsrBwdParams {
     const float *view, *proj;
     const int *radii;
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dscales, *dL_drotations;
+    const uint32_t *row_range;  // as in GsrFwdParams
 };
+
+#if defined(__HIPCC__)
+// The rows of one view: without a row range rows [0, P); with one, rows [begin, end) of the batch-wide arrays, at most `cap` of them
+// (wave-uniform scalar loads).  first = row of the view's Gaussian 0, n = number of Gaussians the kernels may touch.
+__device__ __forceinline__ void gsr_view_rows(const uint32_t *__restrict__ row_range, int cap, uint32_t &first, int &n) {
+    first = 0u;
+    n = cap;
+    if (row_range) {
+        first = row_range[0];
+        const uint32_t m = row_range[1] - first;
+        n = m > (uint32_t)cap ? cap : (int)m;
+    }
+}
+#endif
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
                                const uint8_t *inst_valid, const float *inst_dop, const GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s);

@@ -108,9 +108,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_fwd(int W, int H, int 
         const size_t npix = (size_t)W * H, q = (size_t)g.py * W + g.px;
         final_T[q] = T;
         n_contrib[q] = last;
-        out_color[q] = C0 + T * bg[0];
-        out_color[npix + q] = C1 + T * bg[1];
-        out_color[2 * npix + q] = C2 + T * bg[2];
+        // a view WITHOUT Gaussians is upstream's zero-initialised image, not the background (it skips every kernel when P == 0); with a
+        // row range the host does not know the count, so the rule is applied here (wave-uniform scalar load)
+        const float bgs = hdr->num_points != 0u ? 1.f : 0.f;
+        out_color[q] = C0 + T * (bgs * bg[0]);
+        out_color[npix + q] = C1 + T * (bgs * bg[1]);
+        out_color[2 * npix + q] = C2 + T * (bgs * bg[2]);
     }
 }
 

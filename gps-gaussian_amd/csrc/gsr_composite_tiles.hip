@@ -125,9 +125,12 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
             final_T[q] = st.T;
             n_contrib[q] = last;
         }
-        out_color[q] = st.C0 + st.T * bg[0];
-        out_color[npix + q] = st.C1 + st.T * bg[1];
-        out_color[2 * npix + q] = st.C2 + st.T * bg[2];
+        // a view WITHOUT Gaussians is upstream's zero-initialised image, not the background (it skips every kernel when P == 0); with a
+        // row range the host does not know the count, so the rule is applied here (wave-uniform scalar load)
+        const float bgs = hdr->num_points != 0u ? 1.f : 0.f;
+        out_color[q] = st.C0 + st.T * (bgs * bg[0]);
+        out_color[npix + q] = st.C1 + st.T * (bgs * bg[1]);
+        out_color[2 * npix + q] = st.C2 + st.T * (bgs * bg[2]);
     }
 }
 

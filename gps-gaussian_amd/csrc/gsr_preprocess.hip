@@ -94,15 +94,26 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t rlo = 0, rhi = 0;
     GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
-    if (i < q.P) {
+    // the view's Gaussians: rows [row0, row0 + nP) of the input / output arrays (row0 = 0, nP = P without a row range); everything
+    // inside the workspace is indexed by i, the Gaussian's number inside the view
+    uint32_t row0;
+    int nP;
+    gsr_view_rows(q.row_range, q.P, row0, nP);
+    if (i == 0) {
+        const uint32_t m = q.row_range ? q.row_range[1] - q.row_range[0] : (uint32_t)q.P;
+        hdr->num_points = m;
+        if (m > (uint32_t)q.P) hdr->row_overflow = 1u;  // more rows than the capacity the call was sized for: k_scan_b reports an overflow
+    }
+    if (i < nP) {
+    const size_t r = (size_t)row0 + (size_t)i;
     const Cam cam = load_cam(q.view, q.proj);
-    const float p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
-    const float col[3] = {q.colors[3 * (size_t)i], q.colors[3 * (size_t)i + 1], q.colors[3 * (size_t)i + 2]};
-    const float op = q.opacities[i];
+    const float p[3] = {q.means3D[3 * r], q.means3D[3 * r + 1], q.means3D[3 * r + 2]};
+    const float col[3] = {q.colors[3 * r], q.colors[3 * r + 1], q.colors[3 * r + 2]};
+    const float op = q.opacities[r];
     // rotation and scale are fetched up front, together with the other inputs (one memory round trip instead of a second one
     // behind the near-plane test; a culled Gaussian wastes 28 bytes)
-    float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
-    float s_raw[3] = {q.scales[3 * (size_t)i], q.scales[3 * (size_t)i + 1], q.scales[3 * (size_t)i + 2]};
+    float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * r);
+    float s_raw[3] = {q.scales[3 * r], q.scales[3 * r + 1], q.scales[3 * r + 2]};
     // keep the compiler from sinking these loads back behind the branch
     __asm__ volatile("" : "+v"(rot.x), "+v"(rot.y), "+v"(rot.z), "+v"(rot.w), "+v"(s_raw[0]), "+v"(s_raw[1]), "+v"(s_raw[2]));
     const float sc[3] = {q.scale_modifier * s_raw[0], q.scale_modifier * s_raw[1], q.scale_modifier * s_raw[2]};
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     dst[0] = o0;
     dst[1] = o1;
     dst[2] = make_float4(o2x, o2y, __uint_as_float(rlo), __uint_as_float(rhi));
-    q.radii[i] = radius;
+    q.radii[r] = radius;
     }
     if (q.goff) {  // training workspace: the slot prefix the backward needs (gradient-record slots = bin-rect cells) falls out here
         __shared__ uint32_t s_w[GSR_BIN_THREADS / 64];
@@ -220,18 +231,22 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
                                                         const uint8_t *__restrict__ inst_valid, const float *__restrict__ inst_dop,
                                                         const GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= q.P) return;
+    uint32_t row0;
+    int nP;
+    gsr_view_rows(q.row_range, q.P, row0, nP);
+    if (i >= nP) return;
+    const size_t r = (size_t)row0 + (size_t)i;  // row of the batch-wide input / gradient arrays (= i without a row range)
     // an overflowed forward rendered nothing: inst_valid / inst_grad were never written (and the slot range may not even fit the
     // workspace), so every Gaussian gets an exact zero gradient instead of a gather over garbage
     const bool rendered = hdr->overflow == 0u;
     float dm[3] = {0.f, 0.f, 0.f}, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
-    if (rendered && q.radii[i] > 0) {
+    if (rendered && q.radii[r] > 0) {
         const Cam cam = load_cam(q.view, q.proj);
         // the per-Gaussian inputs of the chain rule are requested BEFORE the record gather, so they travel alongside it
-        float in_p[3] = {q.means3D[3 * (size_t)i], q.means3D[3 * (size_t)i + 1], q.means3D[3 * (size_t)i + 2]};
-        float4 in_rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * (size_t)i);
-        float in_s[3] = {q.scales[3 * (size_t)i], q.scales[3 * (size_t)i + 1], q.scales[3 * (size_t)i + 2]};
+        float in_p[3] = {q.means3D[3 * r], q.means3D[3 * r + 1], q.means3D[3 * r + 2]};
+        float4 in_rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * r);
+        float in_s[3] = {q.scales[3 * r], q.scales[3 * r + 1], q.scales[3 * r + 2]};
         __asm__ volatile("" : "+v"(in_p[0]), "+v"(in_p[1]), "+v"(in_p[2]), "+v"(in_rot.x), "+v"(in_rot.y), "+v"(in_rot.z), "+v"(in_rot.w),
                          "+v"(in_s[0]), "+v"(in_s[1]), "+v"(in_s[2]));
         // gather this Gaussian's instance records in rect order: fixed summation order -> reproducible gradients
@@ -362,13 +377,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         dq[2] = 2.f * (qx * (dR[0][1] + dR[1][0]) + qr * (dR[0][2] - dR[2][0]) + qz * (dR[1][2] + dR[2][1])) - 4.f * qy * (dR[0][0] + dR[2][2]);
         dq[3] = 2.f * (qr * (dR[1][0] - dR[0][1]) + qx * (dR[0][2] + dR[2][0]) + qy * (dR[1][2] + dR[2][1])) - 4.f * qz * (dR[0][0] + dR[1][1]);
     }
-    const size_t i3 = 3 * (size_t)i;
+    const size_t i3 = 3 * r;
     q.dL_dmeans3D[i3] = dm[0]; q.dL_dmeans3D[i3 + 1] = dm[1]; q.dL_dmeans3D[i3 + 2] = dm[2];
     q.dL_dmeans2D[i3] = dm2[0]; q.dL_dmeans2D[i3 + 1] = dm2[1]; q.dL_dmeans2D[i3 + 2] = 0.f;
     q.dL_dcolors[i3] = dcol[0]; q.dL_dcolors[i3 + 1] = dcol[1]; q.dL_dcolors[i3 + 2] = dcol[2];
-    q.dL_dopacity[i] = dop;
+    q.dL_dopacity[r] = dop;
     q.dL_dscales[i3] = dsc[0]; q.dL_dscales[i3 + 1] = dsc[1]; q.dL_dscales[i3 + 2] = dsc[2];
-    *reinterpret_cast<float4 *>(q.dL_drotations + 4 * (size_t)i) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    *reinterpret_cast<float4 *>(q.dL_drotations + 4 * r) = make_float4(dq[0], dq[1], dq[2], dq[3]);
 }
 
 }  // namespace

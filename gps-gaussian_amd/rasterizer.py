@@ -111,7 +111,7 @@ def _drain_pending(st, block=False):
             ev.synchronize()
         if ev.query():
             R, overflow, need = _decode(hdr)
-            _learn(st, R, need, P)
+            _learn(st, R, need, P if P is not None else int(hdr[3]) & 0xffffffff, (int(hdr[1]) >> 32) & 0xffffffff)
             if overflow:
                 st["pending"] = []
                 raise RuntimeError(
@@ -130,12 +130,15 @@ def _decode(hdr):
     return R, overflow, max(R, slots)
 
 
-def _learn(st, R, need, P):
+def _learn(st, R, need, P, longest=None):
     with _lock:  # read-modify-write of monotone maxima
         st["last_R"] = R
-        if P > 0:
+        if P is not None and P > 0:
             st["ratio"] = max(st["ratio"], need / P)
+            st["last_points"] = P
         st["floor"] = max(st["floor"], min(int(need * 1.25) + 4096, 0x7fffffff))
+        if longest is not None:
+            st["longest"] = longest  # the next view's work-order hint (GsrViewExt.order_hint): longest bin list of this one
 
 
 def _ptr(t):
@@ -143,17 +146,21 @@ def _ptr(t):
 
 
 class _HeaderRing:
-    """Pinned 32-byte header slots + reusable events (allocating pinned memory / events per call costs tens of us)."""
+    """Pinned 32-byte header slots + reusable events (allocating pinned memory / events per call costs tens of us).
+
+    Two uses: `next()` hands out slots round-robin for header COPIES (the caller bounds the number in flight: _drain_pending), and
+    `acquire_notify()` / `release()` hand out slots the scan kernel writes directly (gsr_forward_notify) with IN-FLIGHT ACCOUNTING: a
+    slot goes back to the free list only after the host has seen its sequence word, and when every slot is out (a batch of more forwards
+    than slots inside one defer_capacity_checks(), nested callers, many threads) the ring GROWS by another pinned chunk instead of
+    reissuing a slot that is still being polled."""
 
     def __init__(self, n=64):
-        self.buf = torch.zeros((n, 4), dtype=torch.int64).pin_memory()  # 32-byte header prefix per slot
-        self.np = self.buf.numpy()  # same memory; plain numpy scalars are much cheaper to read than 0-d tensors
-        self.base = self.buf.data_ptr()
-        self.events = [torch.cuda.Event() for _ in range(n)]
         self.n, self.i = n, 0
-
-        self.np32 = self.np.view("uint32")  # [n, 8]; word 7 of a slot is the early-notification sequence number
+        self.chunks = []  # (int64 [n,4] view, uint32 [n,8] view: word 7 of a slot = sequence number, base address, the pinned tensor)
+        self.free = []
         self.seq = 0
+        self._grow()
+        self.np, self.base, self.events = self.chunks[0][0], self.chunks[0][2], [torch.cuda.Event() for _ in range(n)]
 
     def next(self):
         with _lock:
@@ -161,13 +168,32 @@ class _HeaderRing:
             self.i = (i + 1) % self.n
         return self.np[i], C.c_void_p(self.base + 32 * i), self.events[i]
 
-    def next_notify(self):
-        """-> (int64[4] header view, uint32[8] view, pointer, sequence number the device will store in word 7)."""
-        with _lock:  # slot and sequence number are handed out together: two host threads never share either
-            i = self.i
-            self.i = (i + 1) % self.n
-            seq = self.seq = self.seq % 0x7fffffff + 1  # never 0, never equal to what the slot holds from its previous use
-        return self.np[i], self.np32[i], C.c_void_p(self.base + 32 * i), seq
+    def acquire_notify(self):
+        """-> (slot handle, int64[4] header view, uint32[8] view, pointer, sequence number the device will store in word 7)."""
+        while True:
+            with _lock:  # slot and sequence number are handed out together: two host threads never share either
+                if self.free:
+                    c, k = slot = self.free.pop()
+                    seq = self.seq = self.seq % 0x7fffffff + 1  # never 0, never equal to what the slot holds from its previous use
+                    arr, a32, base, _ = self.chunks[c]
+                    return slot, arr[k], a32[k], C.c_void_p(base + 32 * k), seq
+            self._grow()
+
+    def _grow(self):
+        buf = torch.zeros((self.n, 4), dtype=torch.int64).pin_memory()  # 32-byte header prefix per slot (allocates pinned memory: outside the lock)
+        arr = buf.numpy()  # same memory; plain numpy scalars are much cheaper to read than 0-d tensors
+        with _lock:
+            c = len(self.chunks)
+            self.chunks.append((arr, arr.view("uint32"), buf.data_ptr(), buf))
+            self.free.extend((c, k) for k in reversed(range(self.n)))
+
+    def release(self, slot):
+        with _lock:
+            self.free.append(slot)
+
+    def in_flight(self):
+        with _lock:
+            return len(self.chunks) * self.n - len(self.free)
 
 
 def _wait_notify(w32, seq, cur_stream):
@@ -186,7 +212,12 @@ def _wait_notify(w32, seq, cur_stream):
 
 
 # ---- several forwards in flight (pts2render: one stream per sample of the batch) ---------------------------------------------------
-_deferred = None  # list collecting the capacity checks of forwards enqueued inside `defer_capacity_checks()`
+_tls = threading.local()  # .deferred: list collecting the capacity checks of forwards this THREAD enqueued inside `defer_capacity_checks()`
+# (per thread: the autograd engine runs backwards -- and recomputed forwards -- on its own threads, and multi-threaded hosts are supported)
+
+
+def _deferred_list():
+    return getattr(_tls, "deferred", None)
 
 
 class defer_capacity_checks:
@@ -196,16 +227,20 @@ class defer_capacity_checks:
     before the context has exited."""
 
     def __enter__(self):
-        global _deferred
-        self.prev, _deferred = _deferred, []
+        self.prev, _tls.deferred = _deferred_list(), []
         return self
 
     def __exit__(self, et, ev, tb):
-        global _deferred
-        todo, _deferred = _deferred, self.prev
+        todo, _tls.deferred = _tls.deferred, self.prev
         if et is None:
             for finish in todo:
                 finish()
+        else:  # an exception is on its way out: still wait for every header (capacity is learnt, pinned slots return to the ring)
+            for finish in todo:
+                try:
+                    finish()
+                except Exception:  # noqa: BLE001
+                    pass
         return False
 
 
@@ -271,12 +306,39 @@ def _device_guard(dev):
     return _NOGUARD if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
-def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, needs_grad, out_color=None):
+class _Rows:
+    """A view whose Gaussians are a ROW RANGE of batch-wide arrays (GsrViewExt.row_range): `offsets` is an int32 device tensor, the view's
+    rows are [offsets[index], offsets[index + 1]); `capacity` bounds their number (it sizes the workspace and the launches).  The host
+    never learns the count: the kernels read the range from the device."""
+
+    __slots__ = ("offsets", "index", "capacity", "ptr")
+
+    def __init__(self, offsets, index, capacity):
+        if offsets.dtype is not torch.int32 or not offsets.is_cuda or not offsets.is_contiguous() or offsets.numel() < index + 2:
+            raise RuntimeError("gps_gaussian_amd: row offsets must be a contiguous int32 GPU tensor with index + 2 entries")
+        self.offsets, self.index, self.capacity = offsets, int(index), int(capacity)
+        self.ptr = offsets.data_ptr() + 4 * self.index
+
+
+def _ext(rows, hint):
+    e = _capi.GsrViewExt()
+    e.row_range = rows.ptr if rows is not None else None
+    e.order_hint = int(hint) & 0xffffffff
+    return e
+
+
+def _too_many(R):
+    return RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace layout can address" % R)
+
+
+def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, needs_grad, out_color=None, rows=None,
+                  radii_out=None):
     """One view's forward through the C-ABI (capacity policy, early notification, overflow repair).  `ctx` is any attribute holder: the
     autograd ctx of _RasterizeGaussians, or a plain namespace when a caller drives several views itself (render_api._RenderBatch).
-    Leaves on it: raster_settings, cap, family, saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws) and, inside
-    defer_capacity_checks(), ws_box.  out_color: optional preallocated contiguous fp32 [3,H,W] the image is written into.
-    -> (color, radii)"""
+    Leaves on it: raster_settings, cap, family, extra_flags, rows, saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws) and,
+    inside defer_capacity_checks(), ws_box.  out_color: optional preallocated contiguous fp32 [3,H,W] the image is written into.
+    rows (a _Rows): the five inputs are batch-wide packed arrays, this view is the row range rows.offsets[rows.index : rows.index + 2] of
+    them (read on the DEVICE), radii_out the batch-wide int32 radii array.  -> (color, radii)"""
     rs = raster_settings
     lib = _capi.lib()
     if not means3D.is_cuda:
@@ -284,20 +346,22 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = means3D.device
-    P = means3D.shape[0]
+    N = means3D.shape[0]                      # rows of the arrays
+    P = N if rows is None else rows.capacity  # Gaussians of the view, or their upper bound
     H, W = int(rs.image_height), int(rs.image_width)
     m3 = _prep(means3D, "means3D", (3,), dev)
     col = _prep(colors_precomp, "colors_precomp", (3,), dev)
     opa = _prep(opacities, "opacities", None, dev).reshape(-1)
     sca = _prep(scales, "scales", (3,), dev)
     rot = _prep(rotations, "rotations", (4,), dev)
-    if not (col.shape[0] == opa.shape[0] == sca.shape[0] == rot.shape[0] == P):
+    if not (col.shape[0] == opa.shape[0] == sca.shape[0] == rot.shape[0] == N):
         raise RuntimeError("all per-Gaussian inputs must have num_points rows")
     view = _cam(rs.viewmatrix, 16, dev)
     proj = _cam(rs.projmatrix, 16, dev)
     bg = _cam(rs.bg, 3, dev)
     family = _composite_flag()
-    flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | family
+    extra = _extra_flags  # read ONCE per view and carried to its backward in ctx (the backward runs on an autograd thread)
+    base_flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | extra | family
     mode = _check_mode()
     st = _dev_state(dev)
     if mode != "none" and torch.cuda.is_current_stream_capturing():
@@ -308,81 +372,89 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             _drain_pending(st)
         cur_stream = torch.cuda.current_stream(dev)
         stream = cur_stream.cuda_stream
-        ring = _ring(dev)
         if out_color is None:
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         else:
             color = out_color
             if (color.dtype is not torch.float32 or color.device != dev or tuple(color.shape) != (3, H, W) or not color.is_contiguous()):
                 raise RuntimeError("gps_gaussian_amd: out_color must be a contiguous fp32 [3, H, W] tensor on the inputs' device")
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        cap = _capacity_for(st, P)
+        if rows is None:
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        else:
+            radii = radii_out
+            if radii is None or radii.dtype is not torch.int32 or radii.device != dev or radii.numel() != N or not radii.is_contiguous():
+                raise RuntimeError("gps_gaussian_amd: a row-range view needs radii_out: contiguous int32 [rows of the arrays] on the inputs' device")
         # inference (no input needs a gradient): skip the backward tail of the workspace (37 B per instance slot)
         ws_bytes = lib.gsr_workspace_bytes if needs_grad else lib.gsr_workspace_bytes_forward_only
-        while True:
+        # a row-range view's P is only a bound: the instance capacity follows the Gaussian counts seen so far on this device
+        p_est = P if rows is None else min(P, int(st.get("last_points", P) * 1.25) + 4096)
+        early = mode == "sync" and P > 0 and _early_notify
+        ring = _ring(dev) if early else None
+
+        def launch(cap):
+            """Enqueue the whole forward against an instance capacity.  -> (workspace, bytes, notify slot or None)"""
             nbytes = ws_bytes(P, W, H, cap)
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-            if mode == "sync" and P > 0 and _early_notify:
-                # the device publishes the instance count to pinned memory right after the binning scan; the host
-                # checks capacity while scatter / sort / compositing are still running (no GPU idle time)
-                hdr, w32, hdr_ptr, seq = ring.next_notify()
-                # the same header carries the longest bin list: as long as none has exceeded 1024 entries on this device,
-                # the (then idle, ~5 us) large-list sort launch is left out -- a surprise is reported like an overflow
-                skip_large = not st.get("big_bins", False)
-                flags = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
-                rc = lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
-                                            float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
-                                            _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
-                                            stream, hdr_ptr, seq)
-                _capi.check(rc, "gsr_forward_notify")
-                if _deferred is not None:
-                    # checked when the enclosing defer_capacity_checks() exits (several views in flight); an overflow is repaired
-                    # there, in place: same output tensors, a larger workspace in ctx.ws_box
-                    box = [ws, cap]
-                    ctx.ws_box = box
+            flags, note = base_flags, None
+            hdr_ptr, seq = None, 0
+            if early:
+                # the device publishes the instance count to pinned memory right after the binning scan; the host checks capacity while
+                # scatter / sort / compositing are still running (no GPU idle time).  The same header carries the longest bin list: as
+                # long as none has exceeded 1024 entries on this device, the (then idle, ~5 us) large-list sort launch is left out -- a
+                # surprise is reported like an overflow
+                slot, hdr, w32, hdr_ptr, seq = ring.acquire_notify()
+                note = (slot, hdr, w32, seq)
+                if not st.get("big_bins", False):
+                    flags |= _capi.GSR_FLAG_NO_LARGE_SORT
+            ext = _ext(rows, st.get("longest", 0))  # work order: longest lists first, relative to the longest list seen on this device
+            rc = lib.gsr_forward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier), float(rs.tanfovx),
+                                    float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
+                                    stream, hdr_ptr, seq, C.byref(ext))
+            if rc != 0 and note is not None:
+                ring.release(note[0])
+            _capi.check(rc, "gsr_forward_ex")
+            return ws, nbytes, note
 
-                    def finish(hdr=hdr, w32=w32, seq=seq, flags=flags):
-                        while True:
-                            _wait_notify(w32, seq, cur_stream)
-                            R, overflow, need = _decode(hdr)
-                            _learn(st, R, need, P)
-                            if int(w32[3]) > 768:
-                                st["big_bins"] = True
-                            if not overflow:
-                                return
-                            if box[1] >= 0x7fffffff:
-                                raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the "
-                                                   "workspace layout can address" % R)
-                            with torch.cuda.stream(cur_stream):
-                                box[1] = _capacity_for(st, P)
-                                nb = ws_bytes(P, W, H, box[1])
-                                box[0] = torch.empty((nb,), dtype=torch.uint8, device=dev)
-                                hdr, w32, hdr_ptr2, seq = ring.next_notify()
-                                fl = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (0 if st.get("big_bins", False) else _capi.GSR_FLAG_NO_LARGE_SORT)
-                                _capi.check(lib.gsr_forward_notify(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot),
-                                                                   float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy), _ptr(view),
-                                                                   _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(box[0]), nb, box[1], fl,
-                                                                   cur_stream.cuda_stream, hdr_ptr2, seq), "gsr_forward_notify")
-
-                    _deferred.append(finish)
-                    break
+        def settle(note, cap):
+            """Wait for a notification and learn from it.  -> (overflowed, R)"""
+            slot, hdr, w32, seq = note
+            try:
                 _wait_notify(w32, seq, cur_stream)
                 R, overflow, need = _decode(hdr)
-                _learn(st, R, need, P)
-                if int(w32[3]) > 768:
-                    st["big_bins"] = True  # sticky, with margin: from now on the large-list sort is always launched
-                if not overflow:
+                npts, longest = int(w32[6]), int(w32[3])
+            finally:
+                ring.release(slot)  # the host has seen the sequence word (or gave up): the slot may be reissued
+            _learn(st, R, need, npts if rows is not None else P, longest)
+            if longest > 768:
+                st["big_bins"] = True  # sticky, with margin: from now on the large-list sort is always launched
+            if overflow and rows is not None and npts > P:
+                raise RuntimeError("gps_gaussian_amd: the row range holds %d Gaussians, more than the capacity of %d rows the view was sized for" % (npts, P))
+            if overflow and cap >= 0x7fffffff:
+                raise _too_many(R)
+            return bool(overflow), R
+
+        cap = _capacity_for(st, p_est)
+        box = None
+        while True:
+            ws, nbytes, note = launch(cap)
+            if note is not None:
+                if _deferred_list() is not None:
+                    # checked when the enclosing defer_capacity_checks() exits (several views in flight); an overflow is repaired there, in
+                    # place: same output tensors, a larger workspace in ctx.ws_box
+                    box = [ws, cap]
+
+                    def finish(note=note):
+                        with torch.cuda.stream(cur_stream):
+                            while settle(note, box[1])[0]:
+                                box[1] = _capacity_for(st, p_est)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
+                                box[0], _, note = launch(box[1])
+
+                    _deferred_list().append(finish)
                     break
-                if cap >= 0x7fffffff:
-                    raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
-                                       "layout can address" % R)
-                cap = _capacity_for(st, P)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
+                if not settle(note, cap)[0]:
+                    break
+                cap = _capacity_for(st, p_est)  # grown by _learn; the in-flight kernels of the failed attempt exit at once on the overflow flag
                 continue
-            flags &= ~_capi.GSR_FLAG_NO_LARGE_SORT  # only the early-notification path can verify that shortcut
-            rc = lib.gsr_forward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
-                                 float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color),
-                                 _ptr(radii), _ptr(ws), nbytes, cap, flags, stream)
-            _capi.check(rc, "gsr_forward")
             if P == 0 or mode == "none":
                 break
             cring = _ring(dev, "copy")
@@ -392,36 +464,45 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             _capi.check(lib.gsr_copy_header_async(_ptr(ws), hdr_ptr, stream), "gsr_copy_header_async")
             ev.record(cur_stream)
             if mode == "deferred":
-                st["pending"].append((ev, hdr, P))
+                st["pending"].append((ev, hdr, P if rows is None else None))
                 break
             ev.synchronize()
             R, overflow, need = _decode(hdr)
-            _learn(st, R, need, P)
+            npts = int(hdr[3]) & 0xffffffff
+            _learn(st, R, need, npts if rows is not None else P, (int(hdr[1]) >> 32) & 0xffffffff)
             if not overflow:
                 break
+            if rows is not None and npts > P:
+                raise RuntimeError("gps_gaussian_amd: the row range holds %d Gaussians, more than the capacity of %d rows the view was sized for" % (npts, P))
             if cap >= 0x7fffffff:
-                raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace "
-                                   "layout can address" % R)
-            cap = _capacity_for(st, P)  # grown by _learn; re-run the whole (cheap) forward
+                raise _too_many(R)
+            cap = _capacity_for(st, p_est)  # grown by _learn; re-run the whole (cheap) forward
     ctx.raster_settings = rs
     ctx.cap = cap
     ctx.family = family  # the backward must repeat the forward's per-pixel decisions: same kernel family
+    ctx.extra_flags = extra
+    ctx.rows = rows
+    if box is not None:
+        ctx.ws_box = box
     ctx.saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws)
     return color, radii
 
 
 def _backward_impl(ctx, saved, grad_out_color, arena):
     """One view's backward through the C-ABI.  saved: the tuple _forward_impl left in ctx.saved; arena: optional five preallocated
-    gradient tensors (means3D, colours, opacities, scales, rotations).  -> (d_m3, d_m2, d_col, d_op, d_sc, d_rot)"""
+    gradient tensors (means3D, colours, opacities, scales, rotations) -- for a row-range view (ctx.rows) they are REQUIRED and batch-wide,
+    the view's rows of them are written.  -> (d_m3, d_m2, d_col, d_op, d_sc, d_rot)"""
     rs = ctx.raster_settings
     lib = _capi.lib()
     m3, col, opa, sca, rot, view, proj, bg, radii, ws = saved
     cap = ctx.cap
+    rows = getattr(ctx, "rows", None)
     box = getattr(ctx, "ws_box", None)
     if box is not None:  # forward ran inside defer_capacity_checks(): the workspace may have been replaced by the overflow repair
         ws, cap = box
     dev = m3.device
-    P = m3.shape[0]
+    N = m3.shape[0]
+    P = N if rows is None else rows.capacity
     H, W = int(rs.image_height), int(rs.image_width)
     g = grad_out_color.detach().to(dtype=torch.float32).contiguous()  # H3: may arrive non-contiguous
     with _device_guard(dev):
@@ -429,10 +510,12 @@ def _backward_impl(ctx, saved, grad_out_color, arena):
         if _check_mode() != "none":
             _drain_pending(st, block=(_check_mode() == "deferred"))
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if arena is not None and all(a.dtype == torch.float32 and a.is_contiguous() and a.device == dev and tuple(a.shape) == (P, c)
-                                     for a, c in zip(arena, (3, 3, 1, 3, 4))):
-            d_m3, d_col, d_op, d_sc, d_rot = arena
-            d_m2 = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        if arena is not None and all(a.dtype == torch.float32 and a.is_contiguous() and a.device == dev and tuple(a.shape) == (N, c)
+                                     for a, c in zip(arena[:5], (3, 3, 1, 3, 4))):
+            d_m3, d_col, d_op, d_sc, d_rot = arena[:5]
+            d_m2 = arena[5] if len(arena) > 5 else torch.empty((N, 3), dtype=torch.float32, device=dev)
+        elif rows is not None:
+            raise RuntimeError("gps_gaussian_amd: a row-range view needs its batch-wide gradient arrays")
         else:
             # one allocation, six contiguous gradient arrays carved out of it (quaternion gradient first: it is stored as float4)
             buf = torch.empty((P * 17,), dtype=torch.float32, device=dev)
@@ -443,11 +526,13 @@ def _backward_impl(ctx, saved, grad_out_color, arena):
             d_sc = buf[13 * P:16 * P].view(P, 3)
             d_op = buf[16 * P:].view(P, 1)
         if P > 0:
-            rc = lib.gsr_backward(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
-                                  float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
-                                  _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
-                                  ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | _extra_flags | ctx.family, stream)
-            _capi.check(rc, "gsr_backward")
+            ext = _ext(rows, 0)
+            rc = lib.gsr_backward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
+                                     float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
+                                     _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
+                                     ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | getattr(ctx, "extra_flags", _extra_flags) | ctx.family,
+                                     stream, C.byref(ext))
+            _capi.check(rc, "gsr_backward_ex")
     return d_m3, d_m2, d_col, d_op, d_sc, d_rot
 
 

@@ -14,11 +14,16 @@ import torch
 from . import rasterizer as _RZ
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
-_stream_pool = {}  # device index -> side streams: the samples of a batch are independent views and render concurrently
+import threading
+
+_tls = threading.local()  # per host thread: device index -> side streams (the samples of a batch are independent views and render concurrently)
 
 
 def _streams(dev, n):
-    pool = _stream_pool.setdefault(dev.index, [])
+    pools = getattr(_tls, "pools", None)
+    if pools is None:
+        pools = _tls.pools = {}
+    pool = pools.setdefault(dev.index, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=dev))
     return pool[:n]
@@ -86,45 +91,52 @@ class _RenderBatch(torch.autograd.Function):
     """All samples of a pts2render batch as ONE autograd node: B raster forwards enqueued back to back on B HIP streams (the views
     are independent and one view leaves the chip under-occupied: DESIGN.md section 4), their exact capacity checks collected and run
     once all are in flight, the images written straight into one [B,3,H,W] tensor; the backward does the same with the B raster
-    backwards, each writing its rows of five batch-wide gradient buffers.  Replaces, per iteration, 5 split nodes + B rasteriser
+    backwards, each writing its rows of six batch-wide gradient buffers.  Replaces, per iteration, 5 split nodes + B rasteriser
     nodes + one concatenation (and their Python), which is what kept the per-sample form host-bound (tools/stage2_ab.py).
-    Numerically it IS the per-sample path: the same C-ABI calls on the same rows (tests/test_gpu_pack.py compares the bits)."""
+
+    The HOST NEVER LEARNS how many valid pixels a sample has: every view is handed the packed batch-wide arrays plus a DEVICE pointer
+    to its {begin, end} row range (GsrViewExt.row_range; the pack kernels' offsets tensor) and a row capacity; the kernels read the range
+    themselves.  The reference learns those counts through ten boolean-mask gathers per sample, each a device sync
+    (lib/GaussianRender.py:15-34); the round-2 form of this class still read the B + 1 offsets back (one sync per batch).
+    Numerically it IS the per-sample path: the same kernels on the same rows (tests/test_gpu_pack.py compares the bits)."""
 
     @staticmethod
-    def forward(ctx, xyz, rgb, rot, scale, opacity, offs, settings):
-        # xyz .. opacity: packed [N, C] fp32 (pack.pack_views); offs: B + 1 row offsets (host ints); settings: B GaussianRasterizationSettings
+    def forward(ctx, xyz, rgb, rot, scale, opacity, offsets, settings, cap_rows):
+        # xyz .. opacity: packed [N, C] fp32 (pack.pack_views); offsets: B + 1 row offsets, int32 ON THE DEVICE; settings: B
+        # GaussianRasterizationSettings; cap_rows: upper bound of a sample's rows (views x pixels)
         bs = len(settings)
         dev = xyz.device
         H, W = int(settings[0].image_height), int(settings[0].image_width)
         out = torch.empty((bs, 3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((xyz.shape[0],), dtype=torch.int32, device=dev)  # batch-wide, like the inputs
         cur = torch.cuda.current_stream(dev)
-        side = _streams(dev, bs) if bs > 1 else [cur]
+        # one HIP stream per sample -- except under graph capture (GPSGS_CHECK=none), where everything stays on the capturing stream
+        side = _streams(dev, bs) if (bs > 1 and not torch.cuda.is_current_stream_capturing()) else [cur] * bs
         needs = any(ctx.needs_input_grad[:5])
         views = []
         with _RZ.defer_capacity_checks():
             for i in range(bs):
-                a, b = offs[i], offs[i + 1]
                 h = _Holder()
                 if side[i] is not cur:
                     side[i].wait_stream(cur)
                 with torch.cuda.stream(side[i]):
-                    _RZ._forward_impl(h, xyz[a:b], rgb[a:b], opacity[a:b], scale[a:b], rot[a:b], settings[i], needs, out_color=out[i])
+                    _RZ._forward_impl(h, xyz, rgb, opacity, scale, rot, settings[i], needs, out_color=out[i],
+                                      rows=_RZ._Rows(offsets, i, cap_rows), radii_out=radii)
                 views.append(h)
         for i in range(bs):
             if side[i] is not cur:
                 cur.wait_stream(side[i])
         # the packed inputs go through save_for_backward (autograd then notices an in-place change between forward and backward); the
-        # per-view holders keep only what is not an input: camera matrices, background, radii, workspace.  (The per-view tensors the
-        # forward used are plain row slices of the packed inputs -- pack_views hands out contiguous fp32 -- and are re-sliced in the
-        # backward; should a slice ever have been converted on the way in, its holder keeps the converted tensors instead.)
+        # per-view holders keep only what is not an input: camera matrices, background, radii, workspace.  (pack_views hands out
+        # contiguous fp32, which _forward_impl uses as is; should an input ever have been converted on the way in, the holder keeps the
+        # converted tensors instead.)
         packed = (xyz, rgb, opacity, scale, rot)  # order of _forward_impl's saved tuple: m3, col, opa, sca, rot
-        for i, h in enumerate(views):
-            a, b = offs[i], offs[i + 1]
-            same = all(sv.data_ptr() == t[a:b].data_ptr() and sv.numel() == t[a:b].numel() for sv, t in zip(h.saved[:5], packed))
+        for h in views:
+            same = all(sv.data_ptr() == t.data_ptr() and sv.numel() == t.numel() for sv, t in zip(h.saved[:5], packed))
             h.tail, h.own = h.saved[5:], (None if same else h.saved[:5])
             h.saved = None
         ctx.save_for_backward(xyz, rgb, rot, scale, opacity)
-        ctx.views, ctx.offs, ctx.side = views, offs, side
+        ctx.views, ctx.side = views, side
         ctx.shapes = tuple(tuple(t.shape) for t in (xyz, rgb, rot, scale, opacity))
         ctx.set_materialize_grads(False)
         return out
@@ -132,26 +144,26 @@ class _RenderBatch(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         if gout is None:
-            return (None,) * 7
-        views, offs, side = ctx.views, ctx.offs, ctx.side
+            return (None,) * 8
+        views, side = ctx.views, ctx.side
         xyz, rgb, rot, scale, opacity = ctx.saved_tensors
         dev = gout.device
         g = gout.detach().to(dtype=torch.float32).contiguous()
-        # one gradient buffer per packed tensor; every view's backward writes its own rows, rows behind offs[-1] (the unused tail of
-        # the packed capacity) are never read by the pack backward
+        # one gradient buffer per packed tensor (+ one for the unused screen-space gradient); every view's backward writes its own
+        # rows, rows behind offsets[-1] (the unused tail of the packed capacity) are never read by the pack backward
         d_xyz, d_rgb, d_rot, d_scale, d_op = (torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes)
+        d_m2 = torch.empty(ctx.shapes[0], dtype=torch.float32, device=dev)
         cur = torch.cuda.current_stream(dev)
         for i, h in enumerate(views):
-            a, b = offs[i], offs[i + 1]
             if side[i] is not cur:
                 side[i].wait_stream(cur)
-            ins = h.own if h.own is not None else (xyz[a:b], rgb[a:b], opacity[a:b].reshape(-1), scale[a:b], rot[a:b])
+            ins = h.own if h.own is not None else (xyz, rgb, opacity.reshape(-1), scale, rot)
             with torch.cuda.stream(side[i]):  # (a workspace replaced by the overflow repair is picked up from h.ws_box in there)
-                _RZ._backward_impl(h, tuple(ins) + tuple(h.tail), g[i], (d_xyz[a:b], d_rgb[a:b], d_op[a:b], d_scale[a:b], d_rot[a:b]))
+                _RZ._backward_impl(h, tuple(ins) + tuple(h.tail), g[i], (d_xyz, d_rgb, d_op, d_scale, d_rot, d_m2))
         for i in range(len(views)):
             if side[i] is not cur:
                 cur.wait_stream(side[i])
-        return d_xyz, d_rgb, d_rot, d_scale, d_op, None, None
+        return d_xyz, d_rgb, d_rot, d_scale, d_op, None, None, None
 
 
 def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color, grad_arena=None):
@@ -196,10 +208,11 @@ def pts2render(data, bg_color):
     """Same contract as the reference's pts2render(): writes data['novel_view']['img_pred'] = [B,3,H,W].
 
     The flatten / mask-gather / concat / rgb-affine of lib/GaussianRender.py:15-34 runs as one fused op for the whole batch
-    (pack.py: 3 launches, no sync) instead of 10 boolean-index gathers + syncs per sample; the only host read is the B+1
-    row offsets that give every sample's tensors their exact shape.  The B renders then run as ONE autograd node with the samples
-    on B HIP streams (_RenderBatch).  GPSGS_PTS2RENDER=loop restores the literal per-sample loop of render() calls (also taken
-    under graph capture and when the samples differ in image size)."""
+    (pack.py: 3 launches, no sync) instead of 10 boolean-index gathers + syncs per sample, and the B + 1 row offsets STAY ON THE
+    DEVICE: the B renders run as ONE autograd node with the samples on B HIP streams, every view reading its row range of the packed
+    arrays from device memory (_RenderBatch) -- with GPSGS_CHECK=none the whole pack -> render -> loss -> backward chain is launches only
+    and can be captured into ONE HIP graph (tests/test_gpu_pack.py).  GPSGS_PTS2RENDER=loop restores the literal per-sample loop of
+    render() calls, which reads the offsets back (also taken when the samples differ in image size)."""
     from .pack import pack_views
 
     bs = data['lmain']['img'].shape[0]
@@ -207,12 +220,11 @@ def pts2render(data, bg_color):
     nv = data['novel_view']
     dev = xyz.device
     sizes_hw = {(int(nv['height'][i]), int(nv['width'][i])) for i in range(bs)}
-    if os.environ.get("GPSGS_PTS2RENDER", "batch") != "loop" and len(sizes_hw) == 1 and not torch.cuda.is_current_stream_capturing():
-        # everything that does not need the row offsets is prepared while the pack kernels run; the offsets' read-back is the one sync
+    if os.environ.get("GPSGS_PTS2RENDER", "batch") != "loop" and len(sizes_hw) == 1:
         bg = _bg_tensor(bg_color, dev)
         view, proj = _to_device_once(nv['world_view_transform'], dev), _to_device_once(nv['full_proj_transform'], dev)
         settings = [_settings(nv, i, bg, view, proj) for i in range(bs)]
-        nv['img_pred'] = _RenderBatch.apply(xyz, rgb, rot, scale, opacity, offsets.tolist(), settings)
+        nv['img_pred'] = _RenderBatch.apply(xyz, rgb, rot, scale, opacity, offsets, settings, xyz.shape[0] // bs)  # no read-back of the offsets
         return data
     return _pts2render_loop(data, bg_color, (xyz, rgb, rot, scale, opacity), offsets.tolist())
 

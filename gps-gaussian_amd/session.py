@@ -87,23 +87,32 @@ class RasterSession:
                                         self.nbytes, cap, flags, stream), "gsr_forward")
             self._pending = None
             return
-        hdr, w32, hdr_ptr, seq = RZ._ring(self.dev).next_notify()
+        ring = RZ._ring(self.dev)
+        slot, hdr, w32, hdr_ptr, seq = ring.acquire_notify()
         skip_large = not st.get("big_bins", False)
         f = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
-        _capi.check(lib.gsr_forward_notify(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
-                                           self.nbytes, cap, f, stream, hdr_ptr, seq), "gsr_forward_notify")
-        self._pending = (hdr, w32, seq)
+        ext = RZ._ext(None, st.get("longest", 0))  # work order: longest lists first, relative to the longest list seen on this device
+        rc = lib.gsr_forward_ex(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
+                                self.nbytes, cap, f, stream, hdr_ptr, seq, C.byref(ext))
+        if rc != 0:
+            ring.release(slot)
+        _capi.check(rc, "gsr_forward_ex")
+        self._pending = (slot, hdr, w32, seq)
 
     def forward_end(self):
         """Second half of forward(): wait until the binning scan has published the instance count (typically well before the forward has
         finished), re-render with a larger workspace if it overflowed.  -> (color, radii)"""
         st = RZ._dev_state(self.dev)
         while self._pending is not None:
-            hdr, w32, seq = self._pending
-            RZ._wait_notify(w32, seq, self._cur)
-            R, overflow, need = RZ._decode(hdr)
-            RZ._learn(st, R, need, self.P)
-            if int(w32[3]) > 768:
+            slot, hdr, w32, seq = self._pending
+            try:
+                RZ._wait_notify(w32, seq, self._cur)
+                R, overflow, need = RZ._decode(hdr)
+                longest = int(w32[3])
+            finally:
+                RZ._ring(self.dev).release(slot)
+            RZ._learn(st, R, need, self.P, longest)
+            if longest > 768:
                 st["big_bins"] = True
             if not overflow:
                 self._pending = None

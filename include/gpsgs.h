@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GPSGS_ABI_VERSION 1
+#define GPSGS_ABI_VERSION 2 /* 2: + GsrViewExt, gsr_forward_ex, gsr_backward_ex; header words num_points / row_overflow (additive) */
 
 enum {
     GPSGS_OK = 0,
@@ -83,7 +83,9 @@ typedef struct GsrHeader {      /* first bytes of the workspace, device memory *
     uint32_t max_tile_count;    /* longest per-bin list (one 8x8-pixel bin = one wave64 work item) */
     uint32_t num_busy_wgs;      /* bins with a non-empty list; they are scheduled first */
     uint32_t num_slots;         /* training workspaces only: bin-rect cells of all Gaussians (one gradient-record slot each); also <= capacity */
-    uint32_t reserved[10];
+    uint32_t num_points;        /* Gaussians of this view: P, or end - begin of GsrViewExt.row_range */
+    uint32_t row_overflow;      /* 1 if a row range held more rows than the P (= row capacity) the call was made with: reported as overflow */
+    uint32_t reserved[8];
 } GsrHeader;
 
 size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity);              /* forward + backward */
@@ -113,6 +115,30 @@ int gsr_forward_notify(int P, int width, int height, const float *means3D, const
                        void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream,
                        void *host_header_out, uint32_t notify_seq);
 
+/* Optional extras of one view (gsr_forward_ex / gsr_backward_ex); zero-initialise, NULL = none.
+ *   row_range   DEVICE pointer to two u32 {begin, end}: the Gaussians of this view are rows [begin, end) of the per-Gaussian input
+ *               arrays AND of the per-Gaussian outputs (radii, the six gradient arrays) -- the arrays are batch-wide, as
+ *               lib/GaussianRender.py:15-34 would leave them if it did not split per sample -- and `P` is only a CAPACITY: it sizes the
+ *               workspace and the launches, the kernels read the real count from the device.  The host then never needs the number of
+ *               valid pixels of a sample (the reference learns it through ten boolean-mask gathers = ten device syncs per sample).
+ *               end - begin > P is reported like an instance overflow (header: row_overflow = 1, num_points = end - begin).
+ *   order_hint  longest per-bin list of an earlier, similar view (header.max_tile_count), 0 = unknown.  The scan dispatches the
+ *               bins whose list exceeds 1/2 and 1/4 of it first (a bin is one wave's sequential job: longest-processing-time-first).
+ *               Decides the ORDER of the work only, never a result. */
+typedef struct GsrViewExt {
+    const uint32_t *row_range;
+    uint32_t order_hint;
+    uint32_t reserved[5];
+} GsrViewExt;
+
+/* gsr_forward_notify + GsrViewExt (host_header_out may be NULL: no notification, like gsr_forward).  The early header's word 6 carries
+ * num_points. */
+int gsr_forward_ex(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                   const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                   const float *viewmatrix, const float *projmatrix, const float *bg, float *out_color, int *radii,
+                   void *workspace, size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream,
+                   void *host_header_out, uint32_t notify_seq, const GsrViewExt *ext);
+
 /* Backward.  Same inputs and the workspace left by the matching gsr_forward, plus dL_dpix[3,H,W] (contiguous).
  * Writes (does not accumulate) dL_dmeans3D[P,3], dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P],
  * dL_dscales[P,3], dL_drotations[P,4]. */
@@ -122,6 +148,14 @@ int gsr_backward(int P, int width, int height, const float *means3D, const float
                  const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors,
                  float *dL_dopacity, float *dL_dscales, float *dL_drotations, void *workspace,
                  size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream);
+
+/* gsr_backward + GsrViewExt (the same row_range the forward was given). */
+int gsr_backward_ex(int P, int width, int height, const float *means3D, const float *colors, const float *opacities,
+                    const float *scales, const float *rotations, float scale_modifier, float tanfovx, float tanfovy,
+                    const float *viewmatrix, const float *projmatrix, const float *bg, const int *radii,
+                    const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors,
+                    float *dL_dopacity, float *dL_dscales, float *dL_drotations, void *workspace,
+                    size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream, const GsrViewExt *ext);
 
 /* Enqueues a copy of the first 32 header bytes {u64 num_rendered, u32 overflow, max_bin_count, num_busy, num_slots, 2 pad} to PINNED host memory on
  * `stream`; does not synchronise (the host reads it after an event / stream sync of its own). */

@@ -147,9 +147,12 @@ class OracleRasterizer:
         d["point_list"] = d["point_list"][:R]
         return d
 
-    def fragility(self):
-        """[H,W] margin map: how close each pixel came to one of the discontinuous branch thresholds."""
+    def fragility(self, power_band=1e-6):
+        """[H,W] margin map: how close each pixel came to one of the discontinuous branch thresholds (alpha = 1/255, T = 1e-4, and --
+        unless power_band = 0 -- an exponent within power_band of upstream's `power > 0` skip)."""
         P, _, _, W, H, _, _ = self.args
         m = np.ones((H, W), self.np)
-        self._f("fragility")(self.h, self._p(m))
+        f = self._f("fragility_ex")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+        f(self.h, self._p(m), float(power_band))
         return m

@@ -155,3 +155,87 @@ def test_batch_with_a_sample_without_valid_points(monkeypatch):
         assert torch.equal(res[mode][0], img_b), mode
         for v in g_b:
             assert torch.equal(res[mode][1][v], g_b[v]), (mode, v)
+
+
+def _stage2_batch(dev, B=2, res=128, seed=5):
+    import torch
+    from gps_gaussian_amd import synthetic as S
+    samples = [S.make_stereo_sample(res, 9000 + 2000 * i, seed=seed + i, render_res=2 * res) for i in range(B)]
+    keys = ("xyz", "img", "rot_maps", "scale_maps", "opacity_maps")
+    data = {}
+    for v in ("lmain", "rmain"):
+        data[v] = {k: torch.from_numpy(np.stack([s[v][k] for s in samples])).to(dev).requires_grad_(True) for k in keys}
+        data[v]["pts_valid"] = torch.from_numpy(np.stack([s[v]["pts_valid"] for s in samples])).to(dev)
+    nv = [s["novel_view"] for s in samples]
+    data["novel_view"] = dict(FovX=torch.tensor([float(c["FovX"]) for c in nv]), FovY=torch.tensor([float(c["FovY"]) for c in nv]),
+                              width=torch.tensor([c["width"] for c in nv]), height=torch.tensor([c["height"] for c in nv]),
+                              world_view_transform=torch.from_numpy(np.stack([c["world_view_transform"] for c in nv])).to(dev),
+                              full_proj_transform=torch.from_numpy(np.stack([c["full_proj_transform"] for c in nv])).to(dev),
+                              camera_center=torch.from_numpy(np.stack([c["camera_center"] for c in nv])))
+    return data, keys
+
+
+def test_pts2render_never_reads_the_row_offsets_back(monkeypatch):
+    """SURVEY section 8(f) row 1, "no host syncs": the batch path hands every view a DEVICE pointer to its row range; no .tolist() /
+    .item() / .cpu() of a GPU tensor happens between the pack and the images (the capacity check reads pinned host memory the scan
+    kernel wrote: not a stream synchronisation)."""
+    import torch
+    from gps_gaussian_amd import render_api
+    dev = torch.device("cuda:0")
+    data, _ = _stage2_batch(dev)
+    render_api.pts2render(data, [0, 0, 0])            # warm-up: capacities learnt
+    torch.cuda.synchronize()
+    data, _ = _stage2_batch(dev)
+    with torch.cuda.stream(torch.cuda.Stream()):      # set_sync_debug_mode does not police the legacy default stream
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            img = render_api.pts2render(data, [0, 0, 0])["novel_view"]["img_pred"]
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert float(img.abs().max()) > 0
+
+
+def test_pack_render_loss_backward_chain_replays_from_one_hip_graph(monkeypatch):
+    """GPSGS_CHECK=none: pack -> B renders -> L1 + SSIM -> backward down to the per-pixel maps is launches + memsets only; captured once,
+    replayed, it reproduces the eager step bit for bit -- also after the maps were changed in place (the row offsets are recomputed
+    on the device inside the graph)."""
+    import torch
+    from gps_gaussian_amd import loss as L
+    from gps_gaussian_amd import render_api
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        data, keys = _stage2_batch(dev)
+        gt = torch.rand(2, 3, 256, 256, device=dev)
+        leaves = [data[v][k] for v in ("lmain", "rmain") for k in keys]
+
+        def step():
+            img = render_api.pts2render(data, [0, 0, 0])["novel_view"]["img_pred"]
+            return img, torch.autograd.grad(L.stage2_photometric_loss(img, gt), leaves)
+
+        img_e, g_e = step()                           # eager, exact capacity check: learns the capacities
+        monkeypatch.setenv("GPSGS_CHECK", "none")
+        step()
+        st.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            img_g, g_g = step()
+        graph.replay()
+        st.synchronize()
+        assert torch.equal(img_g, img_e)
+        for a, b in zip(g_g, g_e):
+            assert torch.equal(a, b)
+        with torch.no_grad():                         # fewer valid pixels in sample 0, other opacities: same graph
+            data["lmain"]["pts_valid"][0, ::3] = False
+            data["rmain"]["opacity_maps"].mul_(0.7)
+        graph.replay()
+        st.synchronize()
+        monkeypatch.setenv("GPSGS_CHECK", "sync")
+        img_e2, g_e2 = step()
+        st.synchronize()
+        assert torch.equal(img_g, img_e2) and not torch.equal(img_e2, img_e)
+        for a, b in zip(g_g, g_e2):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import kat_cases
-from conftest import GOLDEN, clamp_active, hip_render, oracle_render, parity_report, touched_by_fragile
+from conftest import GOLDEN, assert_grad_parity, clamp_active, hip_render, oracle_render, parity_report, touched_by_fragile
 
 pytestmark = pytest.mark.gpu
 
@@ -146,7 +146,7 @@ def test_forward_backward_parity(name, family):
     # --- image
     solid, touched = touched_by_fragile(o)
     err = np.abs(img - oimg).max(0)
-    parity_report("parity[%s-%s]" % (family, name), img, oimg, grads, o.backward(dpix), solid, touched)
+    parity_report("parity[%s-%s]" % (family, name), img, oimg, grads, o.backward(dpix), solid, touched, visible=vis)
     assert solid.mean() > 0.995
     assert err[solid].max() <= RGB_TOL, "max err %.3e" % err[solid].max()
     assert err.max() <= 2.0 / 255 + 1e-3          # a flipped branch changes a pixel by at most one ~1/255 contribution
@@ -189,8 +189,9 @@ def test_config2_full_size_vs_oracle_and_properties():
     err = np.abs(img - oimg).max(0)
     assert err[solid].max() <= RGB_TOL and (err > RGB_TOL).sum() <= 100 and solid.mean() > 0.998
     og = o.backward(dpix)
-    parity_report("config2_1024_600k", img, oimg, grads, og, solid, touched)
+    parity_report("config2_1024_600k", img, oimg, grads, og, solid, touched, visible=oradii > 0)
     _assert_full_size_grads(grads, og, touched)
+    assert ((oradii > 0) & ~touched).sum() >= 0.5 * (oradii > 0).sum()      # the strict set is most of the cloud
 
     # determinism of the forward (sort is on unique 64-bit keys, compositing order fixed): bit-identical re-run
     img2, _, _, _ = hip_render(g)
@@ -237,9 +238,8 @@ def test_every_sort_path(n, expect_path):
     solid, touched = touched_by_fragile(o)
     assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
     og = o.backward(dpix)
-    for k in grads:
-        e = _norm_err(grads[k], og[k])
-        assert np.quantile(e[~touched], 0.999) <= GRAD_TOL if (~touched).any() else True, k
+    frac = assert_grad_parity(grads, og, touched, oradii > 0)
+    parity_report("sort_path[%s]" % expect_path, img, oimg, grads, og, solid, touched, visible=oradii > 0, extra=dict(longest_list=longest))
 
 
 @pytest.mark.parametrize("early", [True, False], ids=["early-notify", "header-copy"])
@@ -394,7 +394,8 @@ def test_config5_2048_highres_2p4M_gaussians():
     solid, touched = touched_by_fragile(o)
     err = np.abs(img - oimg).max(0)
     og = o.backward(dpix)
-    parity_report("config5_2048_2p4M", img, oimg, grads, og, solid, touched)
+    parity_report("config5_2048_2p4M", img, oimg, grads, og, solid, touched, visible=oradii > 0)
+    assert ((oradii > 0) & ~touched).sum() >= 0.5 * (oradii > 0).sum()
     assert solid.mean() > 0.998 and err[solid].max() <= RGB_TOL and (err > RGB_TOL).sum() <= 400
     st = RZ.export_state(info["ws"], 2_400_000, 2048, 2048, info["cap"])
     assert st["overflow"] == 0 and st["num_rendered"] > 2_400_000
@@ -491,13 +492,8 @@ def test_fuzz_odd_shapes_and_degenerate_clouds(cfg, family):
         assert err[solid].max() <= RGB_TOL, "max err %.3e" % err[solid].max()
     assert err.max() <= 2.0 / 255 + 1e-3
     og = o.backward(dpix)
-    parity_report("fuzz[%s-%dx%d_P%d]" % (family, W, H, P), img, oimg, grads, og, solid, touched)
-    for k in grads:
-        assert np.isfinite(grads[k]).all(), k
-        e = _norm_err(grads[k], og[k])
-        if (~touched).any():
-            assert e[~touched].max() <= _max_tol(family, k), "%s: %.3e" % (k, e[~touched].max())
-        assert np.abs(grads[k][oradii == 0]).max(initial=0.0) == 0.0
+    parity_report("fuzz[%s-%dx%d_P%d]" % (family, W, H, P), img, oimg, grads, og, solid, touched, visible=oradii > 0)
+    assert_grad_parity(grads, og, touched, oradii > 0)
 
 
 def test_very_wide_image_takes_the_two_launch_scan():
@@ -512,9 +508,8 @@ def test_very_wide_image_takes_the_two_launch_scan():
     solid, touched = touched_by_fragile(o)
     assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
     og = o.backward(dpix)
-    for k in grads:
-        e = _norm_err(grads[k], og[k])
-        assert e[~touched].max() <= GRAD_TOL, k
+    parity_report("wide_4096x2104", img, oimg, grads, og, solid, touched, visible=oradii > 0)
+    assert assert_grad_parity(grads, og, touched, oradii > 0) >= 0.2
 
 
 def test_forward_backward_under_hip_graph_capture(monkeypatch):
@@ -677,7 +672,8 @@ def test_config2_rendered_at_2048_use_hr_img():
     np.testing.assert_array_equal(radii, oradii)
     solid, touched = touched_by_fragile(o)
     og = o.backward(dpix)
-    parity_report("config2_hr_2048_from_1024", img, oimg, grads, og, solid, touched)
+    parity_report("config2_hr_2048_from_1024", img, oimg, grads, og, solid, touched, visible=oradii > 0)
+    assert ((oradii > 0) & ~touched).sum() >= 0.5 * (oradii > 0).sum()
     err = np.abs(img - oimg).max(0)
     assert solid.mean() > 0.998 and err[solid].max() <= RGB_TOL and (err > RGB_TOL).sum() <= 400
     _assert_full_size_grads(grads, og, touched)
@@ -706,15 +702,12 @@ def test_fov_clamp_rotated_camera_nonunit_quaternions_scale_modifier(cfg, family
     contributing = np.abs(og["means3D"]).max(1) > 0
     frac = (clamp_active(g) & contributing).sum() / max(1, contributing.sum())
     solid, touched = touched_by_fragile(o)
-    parity_report("clamp[%s-%dx%d_P%d_mod%g]" % (family, W, H, P, mod), img, oimg, grads, og, solid, touched,
+    parity_report("clamp[%s-%dx%d_P%d_mod%g]" % (family, W, H, P, mod), img, oimg, grads, og, solid, touched, visible=oradii > 0,
                   extra=dict(contributing=int(contributing.sum()), clamp_active_frac_of_contributing=float(frac)))
     assert contributing.sum() >= P // 20 and frac >= 0.05
     err = np.abs(img - oimg).max(0)
     assert err[solid].max() <= RGB_TOL, "max err %.3e" % err[solid].max()
-    for k in grads:
-        e = _norm_err(grads[k], og[k])
-        assert e[~touched].max() <= _max_tol(family, k), "%s: %.3e" % (k, e[~touched].max())
-        assert np.abs(grads[k][oradii == 0]).max(initial=0.0) == 0.0
+    assert_grad_parity(grads, og, touched, oradii > 0)
 
 
 def test_fused_scan_with_eight_concurrent_streams_and_a_chip_filling_kernel(monkeypatch):
@@ -880,3 +873,71 @@ def test_exact_bin_culling_is_sound_for_needle_shaped_splats(seed):
           "conic condition numbers up to %.1e" % (seed, checked, dropped, worst, 1 / 255, max(cond)))
     assert dropped > checked // 4 and max(cond) > 1e4
     assert worst < 1.0 / 255.0
+
+
+def test_eighty_forwards_inside_one_deferred_check_context():
+    """More forwards in flight than the pinned notification ring has slots (64): the ring must hand out slots with in-flight accounting
+    (and grow) instead of reissuing one that is still being polled.  Every image must equal the blocking result."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    dev = torch.device("cuda:0")
+    g = S.make_uniform_cloud(3000, 96, 80, seed=5, scale_med=0.08)
+    ref, _, _, _ = hip_render(g)
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    t = {k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32)).to(dev) for k in names}
+    rs = RZ.GaussianRasterizationSettings(g["H"], g["W"], g["tanfovx"], g["tanfovy"], torch.from_numpy(g["bg"]).to(dev), 1.0,
+                                          torch.from_numpy(g["view"]).to(dev), torch.from_numpy(g["proj"]).to(dev), 3,
+                                          torch.from_numpy(g["campos"]).to(dev), False, False)
+    rast = RZ.GaussianRasterizer(rs)
+    imgs = []
+    ring = RZ._ring(dev)
+    with torch.no_grad(), RZ.defer_capacity_checks():
+        for _ in range(80):
+            imgs.append(rast(means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"], scales=t["scales"],
+                             rotations=t["rotations"])[0])
+        assert ring.in_flight() >= 80          # none of the 80 notifications has been consumed yet, and none shares a slot
+    torch.cuda.synchronize()
+    assert ring.in_flight() == 0
+    for im in imgs:
+        np.testing.assert_array_equal(im.cpu().numpy(), ref)
+
+
+def test_two_host_threads_render_batches_concurrently():
+    """pts2render from two host threads at once, each on its own stream (SURVEY section 8(b) "Threading / streams": re-entrant; the
+    autograd engine calls the backward from its own threads): the per-thread deferred-check lists must not mix, results equal the
+    single-threaded ones bit for bit."""
+    import threading
+    import torch
+    from gps_gaussian_amd import render_api
+    from test_gpu_pack import _stage2_batch
+    dev = torch.device("cuda:0")
+
+    def run(seed, out, stream=None):
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
+            data, keys = _stage2_batch(dev, seed=seed)
+            img = render_api.pts2render(data, [0, 0, 0])["novel_view"]["img_pred"]
+            gout = torch.ones_like(img)
+            img.backward(gout)
+            torch.cuda.current_stream().synchronize()
+            out[seed] = (img.detach().clone(), data["lmain"]["opacity_maps"].grad.clone())
+
+    single = {}
+    run(11, single); run(31, single)
+    for rep in range(3):
+        multi, errs = {}, []
+
+        def guarded(seed):
+            try:
+                run(seed, multi, torch.cuda.Stream())
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=guarded, args=(s,)) for s in (11, 31)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for s in (11, 31):
+            assert torch.equal(multi[s][0], single[s][0]) and torch.equal(multi[s][1], single[s][1]), (rep, s)

@@ -232,7 +232,7 @@ def test_reference_network_reg_cuda_equals_reg():
         assert fe < 1e-3, fe
         assert abs(na - nb) <= 0.001 * nb and nb > 1000, (na, nb)
         assert torch.isfinite(ia).all() and float((ia - ib).abs().mean()) < 1e-3, float((ia - ib).abs().mean())
-        print("REFERENCE_NETWORK flow_rel_err=%%.2e valid=%%d img_mean_abs_diff=%%.2e" %% (fe, nb, float((ia - ib).abs().mean())))
+        print("REFERENCE_NETWORK flow_rel_err=%.2e valid=%d img_mean_abs_diff=%.2e" % (fe, nb, float((ia - ib).abs().mean())))
     """)
     assert "REFERENCE_NETWORK" in out
 

@@ -215,9 +215,47 @@ def train(args):
     return out
 
 
+def ddp(args):
+    """tools/launch_stage2.py (the data-parallel entry; world size from the torchrun environment, 1 without it) around the reference's
+    Trainer with the REAL networks, data set class and losses; per-iteration hipEvent spans of the reference's own calls."""
+    import numpy as np
+
+    ref = refenv.reference_dir(args.reference)
+    if ref is None:
+        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+    work = os.path.abspath(args.work)
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0:
+        data_root = _dataset(work, args.res, args.train_samples, 2, args.fill)
+        refenv.make_workdir(ref, work, {"stage1_ckpt": "None", "dataset": {"src_res": args.res, "data_root": data_root}})
+    import launch_stage2
+    tfile = os.path.join(work, "timing_rank0.json")
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        launch_stage2.main(["--reference", ref, "--workdir", work, "--steps", str(args.steps), "--exp-root", os.path.join(work, "experiments"), "--timing", tfile,
+                            "batch_size", str(args.batch), "record.loss_freq", str(max(2, args.steps // 2)), "record.eval_freq", str(args.eval_freq or 10 * args.steps)])
+    if rank != 0:
+        return None
+    line = json.loads([l for l in buf.getvalue().splitlines() if l.startswith("{")][-1])
+    t = json.load(open(tfile))
+    half = len(t["iter_ms"]) // 2
+    med = lambda v: round(float(np.median(v[len(v) // 2:])), 3)  # noqa: E731  (second half: after MIOpen / allocator / capacity warm-up)
+    out = {"mode": "ddp", "reference": ref, "res": args.res, "render": "%dx%d" % (2 * args.res, 2 * args.res), "batch_per_gpu": args.batch, "world_size": line["world_size"],
+           "steps": line["steps"], "backend": line["backend"], "exchange": line["exchange"],
+           "iter_ms_median_second_half": med(t["iter_ms"]), "iters_per_s": round(1e3 / med(t["iter_ms"]), 3),
+           "gpu_ms_per_iter": {k: med(v) for k, v in t.items() if k != "iter_ms"},
+           "note": "iter_ms = host time between optimizer steps (includes the DataLoader and the reference's per-iteration .item() syncs); gpu_ms_per_iter = "
+                   "hipEvent spans around the reference's own calls: network_forward = RtStereoHumanModel (RAFT-Stereo + regressor, AMP), pts2render = the "
+                   "reference's per-sample mask gathers + render() -> HIP rasteriser forward, loss_* = lib/loss.py, backward = autograd incl. the HIP rasteriser backward"}
+    print(json.dumps(out))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
-    ap.add_argument("mode", choices=("interp", "train"))
+    ap.add_argument("mode", choices=("interp", "train", "ddp"))
     ap.add_argument("--reference", default=None)
     ap.add_argument("--work", default=os.environ.get("GPSGS_REF_WORK", "/tmp/gpsgs_ref_work"))
     ap.add_argument("--res", type=int, default=1024, help="source resolution (dataset.src_res); the render is 2x that (use_hr_img)")
@@ -230,7 +268,7 @@ def main():
     ap.add_argument("--eval-freq", type=int, default=0)
     ap.add_argument("--write-images", action="store_true")
     args = ap.parse_args()
-    return interp(args) if args.mode == "interp" else train(args)
+    return {"interp": interp, "train": train, "ddp": ddp}[args.mode](args)
 
 
 if __name__ == "__main__":
