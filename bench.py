@@ -97,6 +97,50 @@ def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, st
                         "20.6 MB of network gradients (RCCL); networks not executed" % batch}
 
 
+def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed):
+    """Secondary measurement (never part of `value`): another BASELINE workload through the same C-ABI sessions as the headline --
+    forward + backward and forward only (inference workspace), one view at a time and `inflight` views in flight, `steps` steps each."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    from gps_gaussian_amd.session import RasterSession
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    lanes = []
+    smp = S.make_stereo_sample(res, gaussians, seed=S.SEED + 77, render_res=render_res)  # one synthetic view; every lane renders its own copy of it
+    g, cam = S.compact_sample(smp), smp["novel_view"]
+    for i in range(inflight):
+        t = {k: torch.from_numpy(g[k]).to(dev) for k in names}
+        P = t["means3D"].shape[0]
+        lanes.append(dict(train=RasterSession(P, render_res, render_res, dev, training=True), infer=RasterSession(P, render_res, render_res, dev, training=False),
+                          stream=torch.cuda.Stream(device=dev), a=(t["means3D"], t["colors"], t["opacities"].reshape(-1), t["scales"], t["rotations"],
+                                                                   torch.from_numpy(cam["world_view_transform"]).to(dev), torch.from_numpy(cam["full_proj_transform"]).to(dev),
+                                                                   rs_proto.bg, math.tan(float(cam["FovX"]) * 0.5), math.tan(float(cam["FovY"]) * 0.5), 1.0),
+                          gout=torch.randn(3, render_res, render_res, device=dev)))
+
+    def run(kind, n, k):  # k steps, n views in flight
+        while k > 0:
+            m = min(n, k)
+            for L in lanes[:m]:
+                with torch.cuda.stream(L["stream"]):
+                    L[kind].forward_begin(*L["a"])
+            for L in lanes[:m]:
+                with torch.cuda.stream(L["stream"]):
+                    L[kind].forward_end()
+                    if kind == "train":
+                        L[kind].backward(L["gout"])
+            k -= m
+
+    out = {"P": int(lanes[0]["a"][0].shape[0]), "render": "%dx%d" % (render_res, render_res), "steps": steps}
+    for kind, label in (("train", "fwd_bwd"), ("infer", "fwd_only")):
+        out[label] = {}
+        for n, nl in ((1, "one_view_in_flight"), (inflight, "%d_views_in_flight" % inflight)):
+            run(kind, n, 2 * n + 3)  # warm-up: capacities learnt, workspaces allocated
+            el = timed(lambda k, kind=kind, n=n: run(kind, n, k), steps, 0, multi=True)
+            out[label][nl] = {"views_per_s": round(steps / el, 1), "ms_per_view": round(el / steps * 1e3, 4)}
+    out["R"] = int(RZ.last_stats(dev).get("last_R", 0))
+    return out
+
+
 def graph_leg(args):
     """Secondary measurement, run by the main bench in a CHILD process (a HIP runtime that mis-handles a capture takes the
     process down, and the headline line must survive that): the same forward + backward step captured once into a HIP graph
@@ -156,7 +200,9 @@ def main():
     ap.add_argument("--render-res", type=int, default=None, help="render resolution (default = --res)")
     ap.add_argument("--gaussians", type=int, default=600_000)
     ap.add_argument("--inflight", type=int, default=6, help="independent views rendered concurrently per GPU (one RasterSession + HIP stream each)")
+    ap.add_argument("--repeats", type=int, default=15, help="timed blocks of EXACTLY --steps steps each; value / ms_per_step are the median block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary `configs` block (config 2 rendered at 2048^2, config 5)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip every secondary leg (autograd module, forward only, deferred check, stage-2 path, HIP graph, CPU rows): with --inflight 1 "
                          "every kernel launch of the run then has the chip to itself (tools/prof_r02.sh profiles that mode for the exclusive durations)")
@@ -323,7 +369,7 @@ def main():
     steps_pipelined(max(10, args.warmup, 2 * F) + 4 * F + args.steps)  # untimed; also lets the clocks settle under the concurrent load (one block's worth)
     torch.cuda.synchronize(dev)
     _capi.timing_read()
-    REPEATS = 5
+    REPEATS = max(3, args.repeats)
     blocks = [timed(steps_pipelined, args.steps, 0, multi=True) for _ in range(REPEATS)]
     dom_live = _capi.timing_read()[dom_stage]
     # Second timed region: the same step, EXACTLY --steps of them, one view in flight, the dominant kernel still bracketed by hipEvents on
@@ -331,10 +377,17 @@ def main():
     # with the chip's peak, and a launch that time-shares the chip with the kernels of F - 1 other views (the headline region above)
     # has no exclusive duration -- there every launch lasts longer while the aggregate rate is higher (its duration is reported too:
     # `headline_region`).
-    el_single = timed(step, args.steps, 5)
+    n_single = max(args.steps, 100)  # its own step count: the roofline's duration is an average over >= 100 exclusive launches
+    el_single = timed(step, n_single, 5)
     dom_excl = _capi.timing_read()[dom_stage]
+    sclk_mhz = None
+    try:
+        sclk_mhz = round(_capi.measure_sclk_mhz(dev), 1)  # shader clock under VALU load, measured (not the 2.4 GHz maximum)
+    except Exception:  # noqa: BLE001
+        sclk_mhz = None
     RZ.set_stage_timing(False)
     elapsed = sorted(blocks)[REPEATS // 2]
+    q1, q3 = sorted(blocks)[REPEATS // 4], sorted(blocks)[(3 * REPEATS) // 4]
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
     R = int(RZ.last_stats(dev).get("last_R", 0))  # measured number of (Gaussian, bin) instances of this view
@@ -366,6 +419,29 @@ def main():
 
     # ---- secondary: the hot path inside one stage-2 training iteration (BASELINE config 4: batch = 4 stereo pairs per GPU) ----
     stage2 = None if args.headline_only else stage2_leg(args, s, dev, rank, local_rank, world, D, timed)
+
+    # ---- secondary: the reference's real render size and the stress configuration (rank 0 at N = 1 only; synthetic clouds of those sizes) ----
+    configs = None
+    if rank == 0 and world == 1 and not args.headline_only and not args.no_configs and (args.res, args.gaussians, W) == (1024, 600000, 1024):
+        configs = {}
+        for cname, (cres, cg, crr) in (("config2_rendered_at_2048 (config/stage2.yaml:14-15 use_hr_img: what stage 2 really renders)", (1024, 600000, 2048)),
+                                       ("config5_2048_2p4M", (2048, 2400000, 2048))):
+            try:
+                configs[cname] = config_leg(cres, cg, crr, dev, max(10, min(args.steps, 30)), 3, rs, timed)
+            except Exception as e:  # noqa: BLE001
+                configs[cname] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+
+    # the full pipeline (BASELINE configs 3 / 4: the reference's own scripts and networks on the drop-in) is measured by tools/run_reference.py
+    # in its own gpurun (MIOpen compiles the networks' convolutions for minutes on a fresh box: not something a default bench run can
+    # carry); its tracked result is REPLAYED here, marked as such
+    full_pipeline = None
+    fp_file = os.path.join(ROOT, "profiles", "full_pipeline.json")
+    if rank == 0 and os.path.exists(fp_file):
+        try:
+            full_pipeline = dict(json.load(open(fp_file)), replayed_from="profiles/full_pipeline.json (tools/run_reference.py on an MI355X; profiles/r03_full_pipeline.md)")
+        except Exception:  # noqa: BLE001
+            full_pipeline = None
 
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------------
     NB = (((W + 7) // 8 + 3) // 4 * 4) * ((H + 7) // 8)  # 8x8-pixel bins (one wave64 each), DESIGN.md section 2
@@ -417,8 +493,10 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_tiles" if (dom.startswith("composite") and RZ._composite_flag()) else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_src,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": dom_us,
+                    "launches_averaged": int(dom_excl[1]) if dom == dom_stage else None,
                     "measured": "hipEvents around the kernel on its launch stream over a timed region of %d steps with ONE view in flight (exclusive "
-                                "duration; profiles/r02_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % args.steps,
+                                "duration; profiles/r03_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % n_single,
+                    "bound_note": "the contract's roofline is HBM; this kernel is VALU-issue bound (valu_issue_frac), its HBM fraction is low by construction (DESIGN.md section 4)",
                     # the same kernel inside the headline region: F views in flight, launches of different views overlap and time-share the chip
                     "headline_region": {"views_in_flight": F, "avg_launch_us": ovl_us,
                                         "frac": (round(alg_bytes[dom] / (ovl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if ovl_us else None)},
@@ -426,7 +504,8 @@ def main():
                     "frac_with_tile_16x16_instances": (round(alg_tile / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if alg_tile else None),
                     # compositing is FP32-VALU bound, not HBM bound: one wave64 VALU instruction holds a SIMD for 4 cycles;
                     # measured instructions (rocprofv3 SQ_INSTS_VALU, same workload) x 4 cycles / (1024 SIMDs x 2.4 GHz x t)
-                    "valu_issue_frac": (round(valu_instr * 4.0 / (1024 * 2.4e9 * dom_us * 1e-6), 4) if valu_instr else None)}
+                    "shader_clock_mhz": sclk_mhz,
+                    "valu_issue_frac": (round(valu_instr * 4.0 / (1024 * (sclk_mhz or 2400.0) * 1e6 * dom_us * 1e-6), 4) if valu_instr else None)}
 
     # ---- CPU baseline: the fp32 oracle on the host cores (rank 0, N=1 only), bounded sample ------------------------------
     cpu = None
@@ -494,7 +573,8 @@ def main():
                     "BASELINE config 2 rendered at 2048^2 (use_hr_img)" if (args.res, args.gaussians, W) == (1024, 600000, 2048) else
                     "BASELINE config 5" if (args.res, args.gaussians, W) == (2048, 2400000, 2048) else "non-BASELINE workload (parity / contract test size)")
         line = {
-            "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward", "value": round(value, 2),
+            "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward, C-ABI session with %d views in flight "
+                      "(through the reference's own GaussianRasterizer API, one view at a time: autograd_api_views_per_s)" % F, "value": round(value, 2),
             "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d (Gaussian, 8x8-bin) instances, "
@@ -505,13 +585,16 @@ def main():
                                           "`single_view_in_flight_views_per_s`" % F,
                        "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)"},
             "repeats_ms_per_step": [round(x / args.steps * 1e3, 4) for x in blocks],
-            "single_view_in_flight_views_per_s": round(world * args.steps / el_single, 2),
+            "ms_per_step_iqr": [round(q1 / args.steps * 1e3, 4), round(q3 / args.steps * 1e3, 4)],
+            "single_view_in_flight_views_per_s": round(world * n_single / el_single, 2),
             "autograd_api_views_per_s": rate(el_api),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
             "forward_only_views_per_s": rate(el_fwd),
             "deferred_check_views_per_s": {"fwd_bwd": rate(el_def), "fwd": rate(el_fwd_def)},
             "stages": per_stage,
             "stage2_path": stage2,
+            "configs": configs,
+            "full_pipeline": full_pipeline,
             "hip_graph_replay": graph_res,
         }
         print(json.dumps(line))

@@ -7,14 +7,15 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
-    "gpsgs_abi_version", "gpsgs_build_info", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
+    "gpsgs_abi_version", "gpsgs_build_info", "gpsgs_measure_sclk", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_selftest", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
     "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
 )
 
-GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE = 0, -1, -2, -3, -4
-_ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "no HIP device"}
+GPSGS_OK, GPSGS_E_INVALID, GPSGS_E_WORKSPACE, GPSGS_E_LAUNCH, GPSGS_E_NO_DEVICE, GPSGS_E_INTERNAL = 0, -1, -2, -3, -4, -5
+_ERR = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failed", -4: "no HIP device",
+        -5: "internal self-check failed (debug mode: inconsistent bin lists)"}
 GSR_FLAG_DEBUG = 1
 GSR_FLAG_NO_LARGE_SORT = 4
 GSR_FLAG_TIMING = 2
@@ -55,6 +56,8 @@ def lib():
     l.gpsgs_abi_version.argtypes = []
     l.gpsgs_build_info.restype = C.c_char_p
     l.gpsgs_build_info.argtypes = []
+    l.gpsgs_measure_sclk.restype = i32
+    l.gpsgs_measure_sclk.argtypes = [vp, C.POINTER(C.c_double), vp]
     l.gsr_workspace_bytes.restype = sz
     l.gsr_workspace_bytes.argtypes = [i32, i32, i32, i64]
     l.gsr_workspace_bytes_forward_only.restype = sz
@@ -125,6 +128,17 @@ def lib():
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("gps_gaussian_amd: %s failed: %s (%d)" % (what, _ERR.get(rc, "unknown"), rc))
+
+
+def measure_sclk_mhz(device=None):
+    """Shader clock (MHz) under a few milliseconds of chip-filling VALU load (gpsgs_measure_sclk); synchronises the current stream."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    scratch = torch.zeros((3,), dtype=torch.int64, device=dev)
+    mhz = C.c_double(0.0)
+    with torch.cuda.device(dev):
+        check(lib().gpsgs_measure_sclk(scratch.data_ptr(), C.byref(mhz), torch.cuda.current_stream(dev).cuda_stream), "gpsgs_measure_sclk")
+    return float(mhz.value)
 
 
 def timing_read():

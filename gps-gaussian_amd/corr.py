@@ -22,35 +22,55 @@ def _args(volume, coords):
     if volume.dtype not in _DT:
         raise RuntimeError("corr_sampler supports float32 and float16 volumes, got %s" % volume.dtype)
     N, H1, W1, W2 = volume.shape
-    if coords.shape[0] != N or tuple(coords.shape[2:]) != (H1, W1):
+    if coords.shape[0] != N or tuple(coords.shape[2:]) != (H1, W1) or coords.device != volume.device:
         raise RuntimeError("coords shape %s does not match volume %s" % (tuple(coords.shape), tuple(volume.shape)))
-    c = coords[:, 0].to(dtype=torch.float32).contiguous()
+    # what core/corr.py:46-49 passes -- `coords[:, [0]] / 2**i`: fp32, contiguous, ONE channel -- is used as is ([N,1,H1,W1] and [N,H1,W1]
+    # are the same memory); anything else is brought into that form
+    if coords.dtype is torch.float32 and coords.shape[1] == 1 and coords.is_contiguous():
+        c = coords
+    else:
+        c = coords[:, 0].to(dtype=torch.float32).contiguous()
     return N, H1, W1, W2, c
 
 
+_lib = None
+
+
+def _call(fn, what, dev, *args):
+    """One C-ABI call on the current stream of `dev`; the device guard (~10 us) is taken only when `dev` is not the current device."""
+    if torch.cuda.current_device() == dev.index:
+        rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        with torch.cuda.device(dev):
+            rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        _capi.check(rc, what)
+
+
 def forward(volume, coords, radius):
-    lib = _capi.lib()
+    global _lib
+    lib = _lib or _capi.lib()
+    _lib = lib
     N, H1, W1, W2, c = _args(volume, coords)
-    v = volume.contiguous()
+    v = volume if volume.is_contiguous() else volume.contiguous()
     out = torch.empty((N, 2 * radius + 1, H1, W1), dtype=v.dtype, device=v.device)
-    with torch.cuda.device(v.device):
-        rc = lib.cs_forward(C.c_void_p(v.data_ptr()), C.c_void_p(c.data_ptr()), C.c_void_p(out.data_ptr()), N, H1, W1, W2,
-                            int(radius), _DT[v.dtype], C.c_void_p(torch.cuda.current_stream(v.device).cuda_stream))
-    _capi.check(rc, "cs_forward")
+    # plain integers: ctypes converts them to the void* / int arguments declared in _capi (boxing them in c_void_p costs ~1 us each)
+    _call(lib.cs_forward, "cs_forward", v.device, v.data_ptr(), c.data_ptr(), out.data_ptr(), N, H1, W1, W2, int(radius), _DT[v.dtype])
     return (out,)
 
 
 def backward(volume, coords, grad_output, radius):
-    lib = _capi.lib()
+    global _lib
+    lib = _lib or _capi.lib()
+    _lib = lib
     N, H1, W1, W2, c = _args(volume, coords)
-    g = grad_output.to(dtype=volume.dtype).contiguous()
+    g = grad_output
+    if g.dtype is not volume.dtype or not g.is_contiguous():
+        g = g.to(dtype=volume.dtype).contiguous()
     if tuple(g.shape) != (N, 2 * radius + 1, H1, W1):
         raise RuntimeError("grad_output must be [N,2r+1,H1,W1]")
     gv = torch.empty((N, H1, W1, W2), dtype=volume.dtype, device=volume.device)
-    with torch.cuda.device(volume.device):
-        rc = lib.cs_backward(C.c_void_p(c.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(gv.data_ptr()), N, H1, W1, W2,
-                             int(radius), _DT[volume.dtype], C.c_void_p(torch.cuda.current_stream(volume.device).cuda_stream))
-    _capi.check(rc, "cs_backward")
+    _call(lib.cs_backward, "cs_backward", volume.device, c.data_ptr(), g.data_ptr(), gv.data_ptr(), N, H1, W1, W2, int(radius), _DT[volume.dtype])
     return (gv,)
 
 

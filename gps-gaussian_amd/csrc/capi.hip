@@ -82,6 +82,30 @@ __global__ void k_export(int P, int T, const GsrSplat *__restrict__ splats, cons
     }
 }
 
+// GPSGS_TRACE only: after the sort, every entry of every bin list must be a Gaussian of the view and the lists must be in key order
+__global__ void k_validate_lists(int P, int NB, const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ bin_cursor, const uint32_t *__restrict__ point_list,
+                                 const GsrSplat *__restrict__ splats, unsigned long long *__restrict__ out) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= NB) return;
+    const uint32_t r0 = bin_offset[b], r1 = bin_offset[b + 1];
+    if (bin_cursor[(size_t)b * GSR_CPAD] != r1) atomicAdd(out + 4, 1ull);  // the scatter pass filled exactly the slots the count pass reserved
+    unsigned long long bad_id = 0, bad_order = 0, bad_rec = 0;
+    uint64_t prev = 0;
+    for (uint32_t k = r0; k < r1; k++) {
+        const uint32_t id = point_list[k];
+        if (id >= (uint32_t)P) { bad_id++; continue; }
+        const GsrSplat s = splats[id];
+        if (!(s.x == s.x) || !(s.A == s.A) || !(s.op == s.op)) bad_rec++;
+        const uint64_t key = ((uint64_t)__float_as_uint(s.depth) << 32) | id;
+        if (k > r0 && key <= prev) bad_order++;
+        prev = key;
+    }
+    if (bad_id) atomicAdd(out + 0, bad_id);
+    if (bad_order) atomicAdd(out + 1, bad_order);
+    if (bad_rec) atomicAdd(out + 2, bad_rec);
+    if (bad_id) atomicMax(out + 3, (unsigned long long)(r1 - r0));
+}
+
 }  // namespace
 
 extern "C" int gpsgs_abi_version(void) { return GPSGS_ABI_VERSION; }
@@ -182,6 +206,24 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
         gsr_launch_sort(L.NB, bin_offset, wg_order, keys, point_list, hdr, (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+    if (trace_on() || (flags & GSR_FLAG_DEBUG)) {  // self-check between the sort and the compositing (synchronises; never in normal operation)
+        GsrHeader h;
+        unsigned long long *d_out = nullptr, h_out[5] = {0, 0, 0, 0, 0};
+        if (hipMemcpy(&h, hdr, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || hipMalloc(&d_out, sizeof(h_out)) != hipSuccess) return GPSGS_E_LAUNCH;
+        (void)hipMemset(d_out, 0, sizeof(h_out));
+        if (!h.overflow) hipLaunchKernelGGL(k_validate_lists, dim3((L.NB + 255) / 256), dim3(256), 0, s, P, L.NB, bin_offset, bin_cursor, point_list, splats, d_out);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost);
+        (void)hipFree(d_out);
+        const bool bad = h_out[0] || h_out[1] || h_out[4];
+        if (trace_on() || bad) {
+            fprintf(stderr, "[gpsgs] header: R=%llu overflow=%u longest=%u busy=%u slots=%u points=%u | lists: ids out of range %llu, out of order %llu, non-finite records %llu, "
+                            "bins whose scatter cursor missed its end %llu (longest list with a bad id %llu)\n",
+                    (unsigned long long)h.num_rendered, h.overflow, h.max_tile_count, h.num_busy_wgs, h.num_slots, h.num_points, h_out[0], h_out[1], h_out[2], h_out[4], h_out[3]);
+            fflush(stderr);
+        }
+        if (bad) return GPSGS_E_INTERNAL;
+    }
     {
         trace("composite_fwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
@@ -282,6 +324,37 @@ extern "C" int gsr_selftest(float *out4_device, void *stream) {
     if (!out4_device) return GPSGS_E_INVALID;
     gsr_launch_selftest(out4_device, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
+// ---- shader-clock measurement (diagnostic): s_memtime ticks once per shader cycle, wall_clock64() at the constant rate the runtime reports
+// (hipDeviceAttributeWallClockRate); a chip-filling grid of dependent FMAs runs for a few milliseconds and wave 0 brackets itself with both.
+namespace {
+__global__ __launch_bounds__(256) void k_sclk(unsigned long long *out, int iters) {
+    float a = (float)threadIdx.x * 1e-3f, b = 1.0001f;
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) a = __builtin_fmaf(a, b, 1e-7f);
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+    if (a == 123.456f) out[2] = 1ull;  // keeps the loop alive
+}
+}  // namespace
+
+extern "C" int gpsgs_measure_sclk(unsigned long long *scratch3_device, double *mhz_host, void *stream) {
+    if (!scratch3_device || !mhz_host) return GPSGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0, rate_khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0)
+        return GPSGS_E_NO_DEVICE;
+    hipLaunchKernelGGL(k_sclk, dim3(2048), dim3(256), 0, s, scratch3_device, 60000);
+    unsigned long long h[2] = {0ull, 0ull};
+    if (hipMemcpyAsync(h, scratch3_device, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess) return GPSGS_E_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return GPSGS_E_LAUNCH;
+    if (h[1] == 0ull) return GPSGS_E_LAUNCH;
+    *mhz_host = (double)h[0] / (double)h[1] * (double)rate_khz * 1e-3;
+    return GPSGS_OK;
 }
 
 extern "C" int gsr_timing_read(float *ms_sum_host, int *launches_host) {

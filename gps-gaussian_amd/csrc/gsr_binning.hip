@@ -243,9 +243,10 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, const uint32
         key = ((uint64_t)__float_as_uint(c.y) << 32) | (uint32_t)i;
         if ((hi & 0xffff) > (lo & 0xffff)) {  // listed somewhere
             const uint32_t area = ((hi & 0xffff) - (lo & 0xffff)) * ((hi >> 16) - (lo >> 16));
-            if (area > 32u) {  // rect too large for the cached mask: the predicate k_preprocess counted with, re-evaluated per cell
+            if (area > 32u) {  // rect too large for the cached mask: the predicate k_preprocess counted with, re-evaluated per cell from the
+                               // record and the threshold k_preprocess left in the mask word (never recomputed here: gsr_hit_from_threshold)
                 const float4 a = rec[0], b = rec[1];
-                hit = gsr_hit_setup(a.x, a.y, a.z, a.w, b.x, b.y);
+                hit = gsr_hit_from_threshold(a.x, a.y, a.z, a.w, b.x, __uint_as_float(mask));
             }
             if (inst_valid) {  // training: "no gradient record yet" for every slot of this Gaussian (replaces a cap-byte memset)
                 const uint32_t s0 = gpart[i >> 10] + goff[i];

@@ -145,6 +145,20 @@ __device__ __forceinline__ GsrHit gsr_hit_setup(float x, float y, float A, float
     h.rC = 1.f / C;
     return h;
 }
+// The same test from a threshold that was computed elsewhere: k_scatter rebuilds the predicate of a Gaussian whose rect is too large for
+// the cached mask from the splat record plus the threshold k_preprocess STORED in the mask word -- it must not call logf() itself: the
+// math library's polynomial is contracted differently in translation units with different flags (measured: one v_add became a v_fmac,
+// thresholds one ulp apart, one (Gaussian, bin) decision in ~10^7 flipped between the count and the scatter pass -- a key slot was then
+// never written and the compositing kernel read a random Gaussian id: config 3 with random network weights, splats of ~40 px radius).
+__device__ __forceinline__ GsrHit gsr_hit_from_threshold(float x, float y, float A, float B, float C, float thr) {
+    _Pragma("clang fp contract(off)")
+    GsrHit h;
+    h.x = x; h.y = y; h.A = A; h.B = B; h.C = C;
+    h.thr = thr;
+    h.rA = 1.f / A;
+    h.rC = 1.f / C;
+    return h;
+}
 // minimum of the quadratic form over the rectangle of pixel centres [X0, X1] x [Y0, Y1] against the (inflated) threshold.
 // The fixed inflation of the threshold (0.2 % + 0.02) covers the difference between this evaluation order and the compositing
 // kernels' exp(); what it cannot cover is the rounding of q itself when the conic is strongly anisotropic or correlated and the terms
@@ -178,7 +192,8 @@ __device__ __forceinline__ bool gsr_bin_hit(const GsrHit &h, int bxi, int byi) {
 }
 
 // Bit k of a hit mask = cell k (row-major inside the rect [x0,x1) x [y0,y1)) passed the exact test.  Rects of more than 32
-// cells are not cached: their cells are re-tested wherever the mask is consumed.
+// cells are not cached: their mask word carries the bits of the test's threshold instead (GsrHit::thr) and their cells are re-tested,
+// with that very threshold, wherever the mask is consumed.
 // hit predicate backed by a cached mask (falls back to the exact test for uncached rects)
 struct GsrMaskedHit {
     GsrHit h;

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
         },
         [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t, uint32_t) {},
         wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS);
+    // rects of more than 32 cells are not cached: k_scatter re-tests their cells, with THIS threshold (see gsr_hit_from_threshold)
+    if ((int)((rhi & 0xffff) - (rlo & 0xffff)) * (int)((rhi >> 16) - (rlo >> 16)) > 32) mask = __float_as_uint(hit.thr);
     if (i < q.P) hitmask[i] = mask;
 }
 

@@ -435,6 +435,12 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
 
         cap = _capacity_for(st, p_est)
         box = None
+        dump = os.environ.get("GPSGS_DUMP_INPUTS")  # debugging aid: the inputs of the LAST forward entered, as an .npz (synchronises)
+        if dump and rows is None:
+            import numpy as _np
+            _np.savez(dump, means3D=m3.cpu().numpy(), colors=col.cpu().numpy(), opacities=opa.cpu().numpy(), scales=sca.cpu().numpy(),
+                      rotations=rot.cpu().numpy(), view=view.cpu().numpy(), proj=proj.cpu().numpy(), bg=bg.cpu().numpy(), W=W, H=H,
+                      tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy), scale_modifier=float(rs.scale_modifier), cap=cap, needs_grad=bool(needs_grad))
         while True:
             ws, nbytes, note = launch(cap)
             if note is not None:

@@ -45,11 +45,14 @@ enum {
     GPSGS_E_INVALID = -1,    /* bad argument (NULL pointer, negative size, unsupported dtype) */
     GPSGS_E_WORKSPACE = -2,  /* workspace_bytes smaller than gsr_workspace_bytes() for these dimensions */
     GPSGS_E_LAUNCH = -3,     /* a HIP launch failed (hipGetLastError != hipSuccess) */
-    GPSGS_E_NO_DEVICE = -4   /* no HIP device */
+    GPSGS_E_NO_DEVICE = -4,  /* no HIP device */
+    GPSGS_E_INTERNAL = -5    /* GSR_FLAG_DEBUG only: the forward's self-check failed (a bin list holds an id that is not a Gaussian of the view, is
+                                out of (depth, index) order, or the scatter pass did not fill exactly the slots the count pass reserved) */
 };
 
 /* flags for gsr_forward / gsr_backward */
-#define GSR_FLAG_DEBUG 1u  /* synchronise and check after every kernel (the reference hard-codes debug=False) */
+#define GSR_FLAG_DEBUG 1u  /* synchronise and check after every kernel (the reference hard-codes debug=False); the forward also validates its
+                              bin lists between the sort and the compositing (GPSGS_E_INTERNAL) */
 #define GSR_FLAG_TIMING 2u /* bracket every stage with hipEvents on `stream`; read them with gsr_timing_read() */
 #define GSR_FLAG_NO_LARGE_SORT 4u /* the caller expects no bin list longer than 1024 entries: the (normally idle) 1024-thread sort
                                     launch is skipped.  If a longer list does turn up, the scan reports it as an OVERFLOW (nothing is
@@ -66,6 +69,10 @@ enum {
 };
 
 int gpsgs_abi_version(void);
+/* Diagnostic (synchronises `stream`): the shader clock in MHz under a chip-filling VALU load of a few milliseconds, from the ratio of
+ * the per-cycle counter (s_memtime) to the constant-rate wall clock.  scratch3_device: 24 bytes of device memory.  bench.py prices the
+ * VALU issue rate with it instead of assuming the 2.4 GHz maximum. */
+int gpsgs_measure_sclk(unsigned long long *scratch3_device, double *mhz_host, void *stream);
 const char *gpsgs_build_info(void); /* "gfx950 <compiler> <date>" */
 
 /* ---- rasteriser ---------------------------------------------------------------------------------------------

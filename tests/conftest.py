@@ -136,12 +136,11 @@ def parity_report(name, img, oimg, grads, og, solid, touched, extra=None, rgb_to
 def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2e-3, strict_min=0.2, strict_max_over=0):
     """The gradient criterion every parity test applies (so that every one of them can FAIL):
       * GLOBAL: over ALL Gaussians, the fraction with any element off by more than grad_tol (normalised error
-        |a - ref| / (|ref| + grad_tol max|ref|)) stays below global_frac;
-      * STRICT: over the visible Gaussians that touch no fragile pixel, at most strict_max_over are over grad_tol -- asserted only when
-        that set is a non-trivial part of the cloud (>= strict_min of the visible Gaussians); when it is not (a few fragile pixels under
-        screen-filling splats touch most of the cloud) the test falls back, explicitly, to a 4x tighter global bound;
+        |a - ref| / (|ref| + grad_tol max|ref|)) stays below global_frac (at least 2 Gaussians are allowed: tiny clouds);
+      * STRICT: over the visible Gaussians that touch no fragile pixel, at most strict_max_over are over grad_tol;
       * invisible Gaussians receive exactly zero.
-    Returns the strict-set fraction."""
+    Returns the strict-set fraction (visible Gaussians touching no fragile pixel / visible Gaussians); where it is below strict_min (a few
+    fragile pixels under screen-filling splats touch most of the cloud) the GLOBAL bound is what carries the test, and the report says so."""
     nvis = int(visible.sum())
     strict = visible & ~touched
     frac = float(strict.sum() / max(1, nvis))
@@ -151,10 +150,10 @@ def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2
         e = np.abs(grads[k] - og[k]) / (np.abs(og[k]) + grad_tol * s_)
         over = (e > grad_tol).any(axis=-1)
         assert np.abs(grads[k][~visible]).max(initial=0.0) == 0.0, k
-        if nvis and frac >= strict_min:
-            assert over.mean() < global_frac, "%s: %.5f of all Gaussians over %g" % (k, over.mean(), grad_tol)
-            assert int((over & strict).sum()) <= strict_max_over, "%s: %d strict-set Gaussians over %g (max err %.3e)" % (
-                k, int((over & strict).sum()), grad_tol, e[strict].max())
-        elif nvis:
-            assert over.mean() < global_frac / 4, "%s: strict set is only %.3f of the visible cloud; global fraction over %g is %.5f" % (k, frac, grad_tol, over.mean())
+        assert int(over.sum()) <= max(2, int(global_frac * over.size)), "%s: %d of %d Gaussians over %g (strict set %.3f of the visible cloud)" % (
+            k, int(over.sum()), over.size, grad_tol, frac)
+        assert int((over & strict).sum()) <= strict_max_over, "%s: %d strict-set Gaussians over %g (max err %.3e)" % (
+            k, int((over & strict).sum()), grad_tol, e[strict].max())
+    if frac < strict_min:
+        print("assert_grad_parity: strict set is %.3f of the visible cloud (< %.2f): the global bound carries this case" % (frac, strict_min))
     return frac

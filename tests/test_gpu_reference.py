@@ -261,7 +261,8 @@ def test_train_stage2_script_runs_unmodified(tmp_path):
     """train_stage2.py as __main__ (one process; BASELINE config 4's iteration at a reduced size): real data set class + DataLoader workers, real
     networks under AMP, the reference's pts2render -> HIP rasteriser, L1 + SSIM, GradScaler backward through the HIP backward, AdamW."""
     res = _tool([os.path.join(ROOT, "tools", "run_reference.py"), "train", "--res", "256", "--steps", "6", "--batch", "2", "--train-samples", "2", "--work", str(tmp_path / "w")])
-    assert res["optimizer_steps"] == 6 and res["final_checkpoint_written"] and res["finite_weights"] and res["total_steps"] == 6, res
+    # (the GradScaler skips the optimizer while it calibrates its loss scale from 65536 down: fewer AdamW steps than iterations is AMP at work)
+    assert 1 <= res["optimizer_steps"] <= 6 and res["final_checkpoint_written"] and res["finite_weights"] and res["total_steps"] == 6, res
     print(res)
 
 
