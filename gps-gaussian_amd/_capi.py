@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
-    "gpsgs_abi_version", "gpsgs_build_info", "gpsgs_measure_sclk", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
+    "gpsgs_abi_version", "gpsgs_build_info", "gpsgs_measure_sclk", "gsr_debug_set_wg_trace", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_selftest", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
     "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
@@ -56,6 +56,8 @@ def lib():
     l.gpsgs_abi_version.argtypes = []
     l.gpsgs_build_info.restype = C.c_char_p
     l.gpsgs_build_info.argtypes = []
+    l.gsr_debug_set_wg_trace.restype = i32
+    l.gsr_debug_set_wg_trace.argtypes = [vp]
     l.gpsgs_measure_sclk.restype = i32
     l.gpsgs_measure_sclk.argtypes = [vp, C.POINTER(C.c_double), vp]
     l.gsr_workspace_bytes.restype = sz

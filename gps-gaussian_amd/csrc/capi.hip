@@ -357,6 +357,8 @@ extern "C" int gpsgs_measure_sclk(unsigned long long *scratch3_device, double *m
     return GPSGS_OK;
 }
 
+extern "C" int gsr_debug_set_wg_trace(unsigned long long *rows_device) { return gsr_set_wg_trace(rows_device) == 0 ? GPSGS_OK : GPSGS_E_LAUNCH; }
+
 extern "C" int gsr_timing_read(float *ms_sum_host, int *launches_host) {
     if (!ms_sum_host || !launches_host) return GPSGS_E_INVALID;
     for (int i = 0; i < GSR_STAGE_COUNT; i++) { ms_sum_host[i] = 0.f; launches_host[i] = 0; }

@@ -18,6 +18,28 @@ namespace {
 
 typedef unsigned long long lanemask_t;
 
+// Development aid (gsr_debug_set_wg_trace, tools/wg_trace.py): when set, lane 0 of every compositing workgroup that did work leaves
+// {wall clock at start, wall clock at end (100 MHz), shader cycles spent, HW_ID | XCC_ID << 32 | list length << 40} in row blockIdx.x
+// (forward) / gridDim.x + blockIdx.x (backward): which SIMD ran which bin when -- the per-SIMD timeline behind the tail / balance numbers
+// of DESIGN.md.  NULL in normal operation (one scalar load and one branch per workgroup).
+__device__ unsigned long long *g_wg_trace = nullptr;
+struct WgTrace {
+    unsigned long long *row, w0, c0;
+    __device__ __forceinline__ WgTrace(unsigned row_index) {
+        unsigned long long *base = g_wg_trace;
+        row = base ? base + 4ull * row_index : nullptr;
+        w0 = row ? wall_clock64() : 0ull;
+        c0 = row ? clock64() : 0ull;
+    }
+    __device__ __forceinline__ void done(unsigned len) const {
+        if (row && threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            row[0] = w0; row[1] = wall_clock64(); row[2] = clock64() - c0;
+            row[3] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xffu) << 32) | ((unsigned long long)len << 40);
+        }
+    }
+};
+
 struct TileFwdState {
     float T, C0, C1, C2;
     uint32_t last_rnd;
@@ -70,6 +92,7 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
                                                             float *__restrict__ out_color, float *__restrict__ final_T,
                                                             uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr) {
     __shared__ float4 sCol[WAVE];  // {opacity, r, g, b} of the 64 staged splats
+    const WgTrace trace(blockIdx.x);
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
     if (hdr->overflow) {  // nothing can be rendered from truncated lists: a deterministic zero image instead of uninitialised memory
@@ -132,6 +155,7 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
         out_color[npix + q] = st.C1 + st.T * (bgs * bg[1]);
         out_color[2 * npix + q] = st.C2 + st.T * (bgs * bg[2]);
     }
+    if (r1 > r0) trace.done(r1 - r0);
 }
 
 // ---- backward: scalar colour-behind recurrence and atomic-free per-instance records as in gsr_composite.hip, exponents from the tiles,
@@ -255,6 +279,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
     __shared__ float4 sAcc[WAVE * 3];  // per staged splat: {dr,dg,db,Sx | Sy,Sxx,Sxy,Syy | 4 partial sums of S0}
     __shared__ float4 sSW[2 * TILE_SW_WORDS / 4];  // phase 1 -> phase 2: s[8 splats][64 pixels], w[8][64], rows XOR-swizzled
     if (hdr->overflow) return;
+    const WgTrace trace(gridDim.x + blockIdx.x);
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     if (list_pos >= hdr->num_busy_wgs) return;  // idle workgroups sit at the end of wg_order
     const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
@@ -384,6 +409,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
     const bool black = __builtin_amdgcn_readfirstlane((int)(bg[0] == 0.f && bg[1] == 0.f && bg[2] == 0.f)) != 0;
     if (black) walk(std::false_type{});
     else walk(std::true_type{});
+    trace.done((unsigned)max_last);
 }
 
 // ---- device self-test of the tile plumbing (gsr_selftest): the SAME device functions the kernels use, on pseudo-random splats
@@ -463,6 +489,10 @@ void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat
     if (wgs <= 0) return;
     hipLaunchKernelGGL(k_composite_bwd_tiles, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
                        dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+}
+
+int gsr_set_wg_trace(unsigned long long *rows_device) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &rows_device, sizeof(rows_device)) == hipSuccess ? 0 : -1;
 }
 
 void gsr_launch_selftest(float *out, hipStream_t s) { hipLaunchKernelGGL(k_selftest_tiles, dim3(1), dim3(64), 0, s, out); }

@@ -69,6 +69,11 @@ enum {
 };
 
 int gpsgs_abi_version(void);
+/* Development aid: rows_device = 2 * bins rows of 4 u64 (zeroed by the caller), or NULL to switch it off.  While set, every tile-compositing
+ * workgroup that did work records {wall clock at start, at end (100 MHz), shader cycles, HW_ID | XCC_ID << 32 | list length << 40} in row
+ * blockIdx (forward) / bins + blockIdx (backward): the per-SIMD timeline tools/wg_trace.py analyses.  Process-wide, not thread-safe. */
+int gsr_debug_set_wg_trace(unsigned long long *rows_device);
+
 /* Diagnostic (synchronises `stream`): the shader clock in MHz under a chip-filling VALU load of a few milliseconds, from the ratio of
  * the per-cycle counter (s_memtime) to the constant-rate wall clock.  scratch3_device: 24 bytes of device memory.  bench.py prices the
  * VALU issue rate with it instead of assuming the 2.4 GHz maximum. */

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""gpurun_out/r03/{config3,config4,config4_script}.json (tools/run_reference.py on an MI355X) -> profiles/full_pipeline.json (replayed by
+bench.py as `full_pipeline`) and profiles/r03_full_pipeline.md.   python tools/make_full_pipeline_report.py [dir] [tag]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(d, name):
+    p = os.path.join(d, name)
+    if not os.path.exists(p):
+        return None
+    lines = [l for l in open(p) if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def main(d, tag):
+    c3, c4, c4s = load(d, "config3.json"), load(d, "config4.json"), load(d, "config4_script.json")
+    out = {"measured_on": "one MI355X (gpurun), random-init network weights, synthetic THuman-like data set on disk (tools/make_synthetic_dataset.py)",
+           "command_config3": "python tools/run_reference.py interp --res 1024 --samples 3 --views 5",
+           "command_config4": "python tools/run_reference.py ddp --res 1024 --steps 24 --batch 4 --train-samples 4"}
+    md = ["# BASELINE configs 3 and 4: the reference's OWN scripts, unmodified, on the HIP drop-in (one MI355X)", "",
+          "The reference (`test_view_interp.py`, `train_stage2.py`, its networks, data-set class, losses) is the bytecode build `oracle/stage_ref.py` leaves in the",
+          "git-ignored `oracle/_ref/GPS-Gaussian`; `tools/run_reference.py` executes the scripts as `__main__` / drives `tools/launch_stage2.py` with",
+          "`gps-gaussian_amd/dropin` ahead on `sys.path`.  Network weights are RANDOM (no checkpoint offline), the data set is synthetic, in the loader's",
+          "on-disk layout.  Random weights make the regressed scales sit at their clamp (0.01 m): splats of ~25-40 px radius at 2048^2, ~30 M",
+          "(Gaussian, bin) instances per view -- 8x the instance count of BASELINE config 2 rendered at 2048^2 (3.8 M) -- so the raster share below is an",
+          "upper bound of what trained weights produce.  The networks run in PyTorch-ROCm (MIOpen), as the north star prescribes.", ""]
+    if c3:
+        g = c3["gpu_ms_per_view"]
+        out["config3"] = {"workload": "test_view_interp.py loop: 1024^2 stereo pair -> %s render, novel_view_nums = %d, P = %d (mean)" % (c3["render"], c3["views_per_sample"], c3["gaussians_per_view"]["mean"]),
+                          "views_per_s_end_to_end_script": c3["script_run"]["views_per_s_end_to_end"], "views_per_s_within_sample": c3["script_run"].get("views_per_s_within_sample"),
+                          "views_per_s_gpu_side": c3["views_per_s_gpu_side"], "gpu_ms_per_view": g, "raster_share_of_gpu_time": c3["raster_share_of_gpu_time"]}
+        md += ["## Config 3 -- `test_view_interp.py` (16-camera-style scene directory, `novel_view_nums=5`, render %s)" % c3["render"], "",
+               "| | |", "|---|---|",
+               "| script as `__main__`, whole run (%d views: model construction, checkpoint load, loader + host rectification per sample, network + render + `.cpu()` per view) | **%.2f views/s** |" % (c3["script_run"]["views"], c3["script_run"]["views_per_s_end_to_end"]),
+               "| views of one sample following each other (no loader in between) | **%.2f views/s** |" % (c3["script_run"].get("views_per_s_within_sample") or 0),
+               "| GPU side only: network + `pts2render` (hipEvents around the reference's own calls) | %.2f views/s |" % c3["views_per_s_gpu_side"],
+               "| network forward (`RtStereoHumanModel`, RAFT-Stereo 3 iterations + regressor, AMP, PyTorch-ROCm) | %.2f ms |" % g["network"],
+               "| `pts2render` (the reference's mask gathers + `render()` -> HIP rasteriser forward) | %.2f ms, of which `render()` %.2f ms |" % (g["pts2render"], g["render"]),
+               "| Gaussians per view | %d .. %d |" % (c3["gaussians_per_view"]["min"], c3["gaussians_per_view"]["max"]),
+               "| raster share of the GPU time | %.1f %% |" % (100 * c3["raster_share_of_gpu_time"]), ""]
+    if c4:
+        g = c4["gpu_ms_per_iter"]
+        tot = sum(g.values())
+        out["config4"] = {"workload": "train_stage2.Trainer through tools/launch_stage2.py, world %d, batch %d pairs per GPU, 1024^2 -> %s" % (c4["world_size"], c4["batch_per_gpu"], c4["render"]),
+                          "iters_per_s": c4["iters_per_s"], "iter_ms": c4["iter_ms_median_second_half"], "gpu_ms_per_iter": g, "exchange": c4["exchange"], "backend": c4["backend"]}
+        md += ["## Config 4 -- `train_stage2.Trainer` via `tools/launch_stage2.py`, world size %d, batch %d stereo pairs per GPU, render %s" % (c4["world_size"], c4["batch_per_gpu"], c4["render"]), "",
+               "| | |", "|---|---|",
+               "| **stage-2 iterations/s** (median of the second half of %d iterations; host time between optimizer steps, DataLoader + the reference's `.item()` syncs included) | **%.3f it/s** (%.1f ms) |" % (c4["steps"], c4["iters_per_s"], c4["iter_ms_median_second_half"]),
+               "| network forward (AMP) | %.1f ms |" % g["network_forward"],
+               "| `pts2render` (reference's own: per-sample mask gathers + 4 x HIP raster forward) | %.2f ms |" % g["pts2render"],
+               "| `l1_loss` + `ssim` (reference's `lib/loss.py`, eager PyTorch at [4,3,2048,2048]) | %.2f + %.2f ms |" % (g["loss_l1"], g["loss_ssim"]),
+               "| `scaler.scale(loss).backward()` (networks + loss + 4 x HIP raster backward) | %.1f ms |" % g["backward"],
+               "| `scaler.step(optimizer)` | %.2f ms |" % g["optimizer_step"],
+               "| sum of the spans | %.1f ms |" % tot,
+               "| exchange step | %s (%s) |" % (c4["exchange"], c4["backend"] or "one rank: not issued"), ""]
+    if c4s:
+        out["config4_script"] = c4s
+        md += ["`train_stage2.py` as `__main__` (one process, same sizes, batch %d): %s optimizer steps of %d iterations (the GradScaler skips steps while it calibrates its scale), "
+               "%.3f it/s over the second half, final checkpoint written, weights finite: %s." % (c4s["batch"], c4s["optimizer_steps"], c4s.get("total_steps", 0), c4s.get("iters_per_s_second_half") or 0, c4s.get("finite_weights")), ""]
+    md += ["The north star's raster-only targets (>= 25 views/s at 1024^2, 600 k Gaussians) are met by three orders of magnitude in `bench.py` (`value`); the full pipeline is",
+           "bounded by the PyTorch-ROCm networks and, in training, by the reference's eager SSIM (the fused L1 + SSIM of `gps_gaussian_amd.loss` takes 0.5 ms for the",
+           "same tensors: a one-line swap a maintainer can make, INTEGRATION.md).", ""]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "full_pipeline.json"), "w"), indent=1)
+    open(os.path.join(ROOT, "profiles", "%s_full_pipeline.md" % tag), "w").write("\n".join(md))
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03"), sys.argv[2] if len(sys.argv) > 2 else "r03")

@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 output of tools/prof_r02.sh into the tracked evidence files:
+"""Turn the rocprofv3 output of tools/prof_r03.sh (prof_r02.sh) into the tracked evidence files:
    gpurun_out/prof_<tag>/{kernel_stats.md, pmc_summary.md, pmc_traffic.json}   (copy them to profiles/ to commit)
 Usage: python tools/make_profiles.py <prof dir> <tag>"""
 import collections, csv, glob, json, os, sys
@@ -23,12 +23,12 @@ def main(d, tag):
                                                                            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
         open(os.path.join(d, out_name), "w").write("\n".join(lines) + "\n")
 
-    stats_table("trace", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --no-cpu-baseline` (the driver's command, shorter), MI355X",
+    stats_table("trace", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --repeats 5 --no-cpu-baseline --no-configs` (the driver's command, shorter), MI355X",
                           "# bench.py renders 6 views concurrently in its headline region (one HIP stream each): the launches of different views overlap and",
                           "# time-share the chip, so a kernel's average duration here mixes its one-view-at-a-time launches (calibration, one-view timed region,",
                           "# secondary legs) with the longer overlapped ones.  The exclusive durations -- what `roofline.avg_launch_us` is -- are in",
                           "# %s_kernel_stats_one_view.md; `roofline.headline_region.avg_launch_us` is the overlapped duration." % tag], "kernel_stats.md")
-    stats_table("trace1", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --no-cpu-baseline --inflight 1 --headline-only`, MI355X: ONE view in flight,",
+    stats_table("trace1", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --repeats 5 --no-cpu-baseline --no-configs --inflight 1 --headline-only`, MI355X: ONE view in flight,",
                            "# every launch has the chip to itself.  These are the exclusive kernel durations: `roofline.avg_launch_us` of bench.py (hipEvents on",
                            "# the launch stream over its one-view timed region) and the `stages` table agree with the avg_us column below."], "kernel_stats_one_view.md")
     # ---- pmc
@@ -37,7 +37,7 @@ def main(d, tag):
         for r in csv.DictReader(open(fn)):
             agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = sorted({c for v in agg.values() for c in v})
-    lines = ["# rocprofv3 --pmc (separate passes: SQ_*, FETCH_SIZE, WRITE_SIZE; no trace domains), mean per launch, same command as %s_kernel_stats.md" % tag,
+    lines = ["# rocprofv3 --pmc (separate passes: SQ_*, FETCH_SIZE, WRITE_SIZE; no trace domains), mean per launch, the ONE-VIEW-IN-FLIGHT command of %s_kernel_stats_one_view.md" % tag,
              "# FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE counts 16 B/lane reads at half size (MI355X_MICROARCH.md) -> traffic = 2 x FETCH + WRITE",
              "", "| kernel | launches | " + " | ".join(counters) + " |", "|---|---|" + "---|" * len(counters)]
     for k, v in sorted(agg.items()):
@@ -46,10 +46,10 @@ def main(d, tag):
     open(os.path.join(d, "pmc_summary.md"), "w").write("\n".join(lines) + "\n")
     # ---- traffic file with the workload
     bench = None
-    for l in open(os.path.join(d, "trace.log"), errors="ignore"):
+    for l in open(os.path.join(d, "trace1.log" if os.path.exists(os.path.join(d, "trace1.log")) else "trace.log"), errors="ignore"):
         if l.startswith("{") and '"metric"' in l:
             bench = json.loads(l)
-    out = {"source": "profiles/%s_pmc_summary.md (rocprofv3 --pmc, separate passes, tools/prof_r02.sh)" % tag}
+    out = {"source": "profiles/%s_pmc_summary.md (rocprofv3 --pmc, separate passes on the one-view-in-flight command, tools/prof_%s.sh)" % (tag, tag)}
     if bench:
         import re
         m = re.search(r"(\d+)x(\d+) render.*P=(\d+) Gaussians, R=(\d+)", bench["config"]["workload"])

@@ -31,7 +31,7 @@ import refenv  # noqa: E402
 
 def _dataset(work, res, n_train, n_val, fill):
     import make_synthetic_dataset as M
-    root = os.path.join(work, "data_%d" % res)
+    root = os.path.join(work, "data_%d_%d_%d_%g" % (res, n_train, n_val, fill))
     if not os.path.isdir(os.path.join(root, "val", "img")):
         M.make_dataset(root, res=res, n_train=n_train, n_val=n_val, fill=fill, quiet=True)
     return root
