@@ -320,6 +320,20 @@ def main():
             group(min(F, k))
             k -= min(F, k)
 
+    def group_s2(n):  # the same with the gradient set stage 2 needs: no dL/dcolour (the colours are input pixels, never differentiated)
+        for L in lanes[:n]:
+            with torch.cuda.stream(L["stream"]):
+                L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
+        for L in lanes[:n]:
+            with torch.cuda.stream(L["stream"]):
+                L["sess"].forward_end()
+                L["sess"].backward(L["gout"], color_grad=False)
+
+    def steps_pipelined_s2(k):
+        while k > 0:
+            group_s2(min(F, k))
+            k -= min(F, k)
+
     sess = lanes[0]["sess"]
 
     def step():  # one view at a time on the current stream (calibration of the per-kernel table, and the single-view-in-flight number)
@@ -385,6 +399,20 @@ def main():
         sclk_mhz = round(_capi.measure_sclk_mhz(dev), 1)  # shader clock under VALU load, measured (not the 2.4 GHz maximum)
     except Exception:  # noqa: BLE001
         sclk_mhz = None
+    # secondary: the stage-2 gradient set (no dL/dcolour), same sessions; the dominant kernel keeps its bracket for the exclusive duration
+    s2 = None
+    if not args.headline_only:
+        def step_s2():
+            L = lanes[0]
+            sess.forward(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
+            sess.backward(L["gout"], color_grad=False)
+        el_s2_one = timed(step_s2, n_single, 5)
+        dom_s2 = _capi.timing_read()[dom_stage]
+        el_s2 = sorted(timed(steps_pipelined_s2, args.steps, 2 * F if i == 0 else 0, multi=True) for i in range(5))[2]
+        _capi.timing_read()
+        s2 = {"gradients": "means3D, means2D, opacities, scales, rotations (GSR_FLAG_NO_COLOR_GRAD: what train_stage2.py differentiates; the colours are input pixels)",
+              "views_per_s": round(world * args.steps / el_s2, 2), "views_in_flight": F, "single_view_in_flight_views_per_s": round(world * n_single / el_s2_one, 2),
+              "dominant_kernel_avg_launch_us": round(dom_s2[0] / max(1, dom_s2[1]) * 1e3, 2) if dom_s2[1] else None}
     RZ.set_stage_timing(False)
     elapsed = sorted(blocks)[REPEATS // 2]
     q1, q3 = sorted(blocks)[REPEATS // 4], sorted(blocks)[(3 * REPEATS) // 4]
@@ -588,6 +616,7 @@ def main():
             "ms_per_step_iqr": [round(q1 / args.steps * 1e3, 4), round(q3 / args.steps * 1e3, 4)],
             "single_view_in_flight_views_per_s": round(world * n_single / el_single, 2),
             "autograd_api_views_per_s": rate(el_api),
+            "stage2_gradient_set": s2,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
             "forward_only_views_per_s": rate(el_fwd),
             "deferred_check_views_per_s": {"fwd_bwd": rate(el_def), "fwd": rate(el_fwd_def)},

@@ -288,7 +288,8 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
         // must be the same family as the forward that filled the workspace: the two designs round the exponent differently, and the
         // backward has to repeat the forward's per-pixel decisions
         if (flags & GSR_FLAG_COMPOSITE_TILES)
-            gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
+            gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr,
+                                           (flags & GSR_FLAG_NO_COLOR_GRAD) == 0, s);
         else
             gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
     }

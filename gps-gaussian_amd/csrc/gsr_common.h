@@ -358,7 +358,7 @@ int gsr_set_wg_trace(unsigned long long *rows_device);  // development aid: per-
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
                                     const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop, GsrGradAcc *inst_grad, const GsrHeader *hdr,
-                                    hipStream_t s);
+                                    bool color_grad /* false: GSR_FLAG_NO_COLOR_GRAD, the colour sums are left out (zeros in the records) */, hipStream_t s);
 void gsr_launch_selftest(float *out4, hipStream_t s);
 struct GsrBwdParams {
     int P, W, H;

@@ -182,16 +182,28 @@ struct TileBwdConst {
 };
 constexpr int TILE_SW_WORDS = 8 * WAVE;  // one array (s or w): 8 splats x 64 pixels
 
-template <int GQ>
+// CG = false: nobody asked for dL/dcolour (GSR_FLAG_NO_COLOR_GRAD -- stage 2: the colours are input pixels, train_stage2.py never
+// differentiates them): the w array is neither written nor read and the three colour sums per (pixel, splat) are left out; their slots of the
+// reduce-scatter carry zeros, so the record layout and every other gradient are bit-identical to the full form
+template <int GQ, bool CG>
 __device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const float4 *__restrict__ wXY, const float (&pxu)[8], int lane) {
     const float4 s0 = k.rdA[0], s1 = k.rdB[0];
-    const float4 w0 = k.rdA[TILE_SW_WORDS / 4], w1 = k.rdB[TILE_SW_WORDS / 4];
     const float2 xy = *reinterpret_cast<const float2 *>(&wXY[8 * GQ + (lane & 7)]);
     const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
     // the sums start from the u = 0 terms (0 + x and fma(a, b, 0) are not folded by the compiler: -0 semantics; same bits)
     const float dx0 = xy.x - pxu[0], mx0 = sv[0] * dx0;
-    float S0 = sv[0], Sx = mx0, Sxx = mx0 * dx0, cr = wv[0] * k.dr[0], cg = wv[0] * k.dg[0], cb = wv[0] * k.db[0];
+    float S0 = sv[0], Sx = mx0, Sxx = mx0 * dx0, cr = 0.f, cg = 0.f, cb = 0.f;
+    if (CG) {
+        const float4 w0 = k.rdA[TILE_SW_WORDS / 4], w1 = k.rdB[TILE_SW_WORDS / 4];
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        cr = wv[0] * k.dr[0]; cg = wv[0] * k.dg[0]; cb = wv[0] * k.db[0];
+#pragma unroll
+        for (int u = 1; u < 8; u++) {
+            cr = __builtin_fmaf(wv[u], k.dr[u], cr);
+            cg = __builtin_fmaf(wv[u], k.dg[u], cg);
+            cb = __builtin_fmaf(wv[u], k.db[u], cb);
+        }
+    }
 #pragma unroll
     for (int u = 1; u < 8; u++) {
         const float dx = xy.x - pxu[u];  // the same single rounding as x - (float)px
@@ -199,9 +211,6 @@ __device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const fl
         S0 += sv[u];
         Sx += mx;
         Sxx = __builtin_fmaf(mx, dx, Sxx);
-        cr = __builtin_fmaf(wv[u], k.dr[u], cr);
-        cg = __builtin_fmaf(wv[u], k.dg[u], cg);
-        cb = __builtin_fmaf(wv[u], k.db[u], cb);
     }
     const float dy = xy.y - k.pyrow;  // constant along the row
     const float Sy = dy * S0, Sxy = dy * Sx;
@@ -219,7 +228,7 @@ __device__ __forceinline__ void tiles_bwd_phase2(const TileBwdConst &k, const fl
 
 // one staged splat of phase 1; inr = lanes whose pixel has this list position among its contributors.  BG = false: the background is
 // black (the reference's stage 2, config/stereo_human_config.py:24), its term of dL/dalpha is an exact zero and is left out
-template <bool BG>
+template <bool BG, bool CG>
 __device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdConst &k, const float4 c, float pe, lanemask_t inr, int e, int j,
                                                float dr, float dg, float db, float nTb) {
     const float aG = __builtin_amdgcn_exp2f(pe);  // opacity * G (the tile holds its log2); as the forward: no power > 0 skip
@@ -239,11 +248,11 @@ __device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdCo
         const float dL_dalpha = BG ? cA * st.T + nTb * rcp : cA * st.T;
         st.A = __builtin_fmaf(ae, cA, st.A);  // = ae cd + (1 - ae) A
         k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
-        k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
+        if (CG) k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
     }
 }
 
-template <int GQ, bool BG>
+template <int GQ, bool BG, bool CG>
 __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &d0, const f32x16 &d1, const float4 *__restrict__ wXY,
                                                 const float4 *__restrict__ wCol, const TileBwdConst &k, const float (&pxu)[8], int lane,
                                                 uint32_t topu, uint32_t last, float dr, float dg, float db, float nTb) {
@@ -259,13 +268,14 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
     for (int e = 0; e < 8; e++) {
         const float4 c = cn;
         if (e < 7) cn = wCol[8 * GQ + e + 1];
-        tiles_bwd_pair<BG>(st, k, c, p[e], __ballot(last > topu - (uint32_t)(8 * GQ + e)), e, 8 * GQ + e, dr, dg, db, nTb);
+        tiles_bwd_pair<BG, CG>(st, k, c, p[e], __ballot(last > topu - (uint32_t)(8 * GQ + e)), e, 8 * GQ + e, dr, dg, db, nTb);
     }
     // splats of the group that no pixel touched leave stale numbers in their rows: their sums are never flushed (touched bit clear)
-    if ((st.touched >> (8 * GQ)) & 0xffull) tiles_bwd_phase2<GQ>(k, wXY, pxu, lane);
+    if ((st.touched >> (8 * GQ)) & 0xffull) tiles_bwd_phase2<GQ, CG>(k, wXY, pxu, lane);
 }
 
 // ~170 VGPRs: 2 waves per SIMD (2 and 3 measured identical: the kernel is VALU-issue bound; forcing 4 spills: 172 us)
+template <bool CG>
 __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
@@ -328,9 +338,9 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int src = (lane & 56) + u;  // the lane whose pixel is (row, u)
-            k.dr[u] = __shfl(d0, src, 64);
-            k.dg[u] = __shfl(d1, src, 64);
-            k.db[u] = __shfl(d2, src, 64);
+            k.dr[u] = CG ? __shfl(d0, src, 64) : 0.f;
+            k.dg[u] = CG ? __shfl(d1, src, 64) : 0.f;
+            k.db[u] = CG ? __shfl(d2, src, 64) : 0.f;
             pxu[u] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pxf - (float)(lane & 7) + (float)u)));
         }
     }
@@ -375,17 +385,17 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
         st.touched = 0ull;
         {
             const f32x16 t0 = pow_tile_bf16(opA.a[0], opB.b[0]), t1 = pow_tile_bf16(opA.a[0], opB.b[1]);
-            if (0 < cnt) tiles_bwd_group<0, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (8 < cnt) tiles_bwd_group<1, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (16 < cnt) tiles_bwd_group<2, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (24 < cnt) tiles_bwd_group<3, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (0 < cnt) tiles_bwd_group<0, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (8 < cnt) tiles_bwd_group<1, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (16 < cnt) tiles_bwd_group<2, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (24 < cnt) tiles_bwd_group<3, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
         }
         if (32 < cnt) {
             const f32x16 t0 = pow_tile_bf16(opA.a[1], opB.b[0]), t1 = pow_tile_bf16(opA.a[1], opB.b[1]);
-            tiles_bwd_group<4, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (40 < cnt) tiles_bwd_group<5, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (48 < cnt) tiles_bwd_group<6, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
-            if (56 < cnt) tiles_bwd_group<7, BG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            tiles_bwd_group<4, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (40 < cnt) tiles_bwd_group<5, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (48 < cnt) tiles_bwd_group<6, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
+            if (56 < cnt) tiles_bwd_group<7, BG, CG>(st, t0, t1, sXY, sCol, k, pxu, lane, topu, last, d0, d1, d2, nTb);
         }
         wave_sync_lds();
         if ((st.touched >> lane) & 1ull) {  // lane j parks staged splat j's sums as ONE 32-byte instance record + its dL/dopacity (no atomics)
@@ -484,11 +494,15 @@ void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
                                     const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop,
-                                    GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
+                                    GsrGradAcc *inst_grad, const GsrHeader *hdr, bool color_grad, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_bwd_tiles, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
-                       dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    if (color_grad)
+        hipLaunchKernelGGL(k_composite_bwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
+                           dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    else
+        hipLaunchKernelGGL(k_composite_bwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
+                           dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }
 
 int gsr_set_wg_trace(unsigned long long *rows_device) {

@@ -76,7 +76,12 @@ class _PackViews(torch.autograd.Function):
         _capi.check(rc, "gsr_pack_views")
         ctx.save_for_backward(row_of_pixel)
         ctx.meta = (n_views, B, S2, [tuple(t.shape) for t in tensors])
-        ctx.mark_non_differentiable(offsets)
+        # the packed colours are differentiable only if some image is (in stage 2 none is: the rasteriser backward then skips dL/dcolour)
+        img_needs = any(ctx.needs_input_grad[1 + v * per + 1] for v in range(n_views))
+        if img_needs:
+            ctx.mark_non_differentiable(offsets)
+        else:
+            ctx.mark_non_differentiable(offsets, out[1])
         return (*out, offsets)
 
     @staticmethod

@@ -494,8 +494,9 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
     return color, radii
 
 
-def _backward_impl(ctx, saved, grad_out_color, arena):
-    """One view's backward through the C-ABI.  saved: the tuple _forward_impl left in ctx.saved; arena: optional five preallocated
+def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
+    """One view's backward through the C-ABI.  color_grad=False: the caller does not need dL/dcolours (GSR_FLAG_NO_COLOR_GRAD: the tile
+    family leaves the colour sums out; the returned colour gradient is zeros / not meaningful).  saved: the tuple _forward_impl left in ctx.saved; arena: optional five preallocated
     gradient tensors (means3D, colours, opacities, scales, rotations) -- for a row-range view (ctx.rows) they are REQUIRED and batch-wide,
     the view's rows of them are written.  -> (d_m3, d_m2, d_col, d_op, d_sc, d_rot)"""
     rs = ctx.raster_settings
@@ -536,8 +537,8 @@ def _backward_impl(ctx, saved, grad_out_color, arena):
             rc = lib.gsr_backward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
                                      _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
-                                     ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | getattr(ctx, "extra_flags", _extra_flags) | ctx.family,
-                                     stream, C.byref(ext))
+                                     ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | getattr(ctx, "extra_flags", _extra_flags) | ctx.family
+                                     | (0 if color_grad else _capi.GSR_FLAG_NO_COLOR_GRAD), stream, C.byref(ext))
             _capi.check(rc, "gsr_backward_ex")
     return d_m3, d_m2, d_col, d_op, d_sc, d_rot
 
@@ -549,6 +550,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         # of batch-wide buffers -- that the backward writes dL/d(means3D, colours, opacities, scales, rotations) into instead of
         # fresh allocations, so that the batch's gradients arrive already concatenated (render_api._SplitRows)
         ctx.grad_arena = grad_arena
+        # stage 2 never differentiates the colours (they are input pixels, lib/GaussianRender.py:30-31): the backward then skips their sums
+        ctx.color_grad = bool(ctx.needs_input_grad[3])
         color, radii = _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, any(ctx.needs_input_grad))
         ctx.save_for_backward(*ctx.saved)
         ctx.saved = None
@@ -560,9 +563,9 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         if grad_out_color is None:  # the image did not take part in the loss
             return (None,) * 10
-        d_m3, d_m2, d_col, d_op, d_sc, d_rot = _backward_impl(ctx, ctx.saved_tensors, grad_out_color, ctx.grad_arena)
+        d_m3, d_m2, d_col, d_op, d_sc, d_rot = _backward_impl(ctx, ctx.saved_tensors, grad_out_color, ctx.grad_arena, ctx.color_grad)
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
-        return d_m3, d_m2, None, d_col, d_op, d_sc, d_rot, None, None, None
+        return d_m3, d_m2, None, (d_col if ctx.color_grad else None), d_op, d_sc, d_rot, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, grad_arena=None):

@@ -137,6 +137,7 @@ class _RenderBatch(torch.autograd.Function):
             h.saved = None
         ctx.save_for_backward(xyz, rgb, rot, scale, opacity)
         ctx.views, ctx.side = views, side
+        ctx.color_grad = bool(ctx.needs_input_grad[1])  # False in stage 2: pack_views marks rgb non-differentiable when no image needs a gradient
         ctx.shapes = tuple(tuple(t.shape) for t in (xyz, rgb, rot, scale, opacity))
         ctx.set_materialize_grads(False)
         return out
@@ -159,11 +160,11 @@ class _RenderBatch(torch.autograd.Function):
                 side[i].wait_stream(cur)
             ins = h.own if h.own is not None else (xyz, rgb, opacity.reshape(-1), scale, rot)
             with torch.cuda.stream(side[i]):  # (a workspace replaced by the overflow repair is picked up from h.ws_box in there)
-                _RZ._backward_impl(h, tuple(ins) + tuple(h.tail), g[i], (d_xyz, d_rgb, d_op, d_scale, d_rot, d_m2))
+                _RZ._backward_impl(h, tuple(ins) + tuple(h.tail), g[i], (d_xyz, d_rgb, d_op, d_scale, d_rot, d_m2), ctx.color_grad)
         for i in range(len(views)):
             if side[i] is not cur:
                 cur.wait_stream(side[i])
-        return d_xyz, d_rgb, d_rot, d_scale, d_op, None, None, None
+        return d_xyz, (d_rgb if ctx.color_grad else None), d_rot, d_scale, d_op, None, None, None
 
 
 def render(data, idx, pts_xyz, pts_rgb, rotations, scales, opacity, bg_color, grad_arena=None):

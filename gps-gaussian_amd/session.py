@@ -123,8 +123,9 @@ class RasterSession:
                 self._enqueue(RZ._capacity_for(st, self.P))  # the in-flight kernels of the failed attempt exit at once on the overflow flag
         return self.color, self.radii
 
-    def backward(self, dL_dpix):
-        """dL_dpix[3,H,W] fp32 contiguous -> dict of gradient tensors (the session's own buffers: valid until the next backward)."""
+    def backward(self, dL_dpix, color_grad=True):
+        """dL_dpix[3,H,W] fp32 contiguous -> dict of gradient tensors (the session's own buffers: valid until the next backward).
+        color_grad=False: dL/dcolours is not needed (stage 2: the colours are input pixels) -- GSR_FLAG_NO_COLOR_GRAD, its buffer holds zeros."""
         if not self.training:
             raise RuntimeError("gps_gaussian_amd: this RasterSession was created with training=False (no backward workspace)")
         if self._in is None:
@@ -135,7 +136,8 @@ class RasterSession:
         if self.P > 0:
             rc = self.lib.gsr_backward(self.P, self.W, self.H, *ptrs, *fl, *cam, self.radii.data_ptr(), g, G["means3D"].data_ptr(),
                                        G["means2D"].data_ptr(), G["colors"].data_ptr(), G["opacities"].data_ptr(), G["scales"].data_ptr(),
-                                       G["rotations"].data_ptr(), self.ws.data_ptr(), self.nbytes, self.cap, RZ._extra_flags | family,
+                                       G["rotations"].data_ptr(), self.ws.data_ptr(), self.nbytes, self.cap,
+                                       RZ._extra_flags | family | (0 if color_grad else _capi.GSR_FLAG_NO_COLOR_GRAD),
                                        torch.cuda.current_stream(self.dev).cuda_stream)
             _capi.check(rc, "gsr_backward")
         return G

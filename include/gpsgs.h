@@ -60,6 +60,10 @@ enum {
 #define GSR_FLAG_COMPOSITE_TILES 8u /* compositing kernels that take the exponents of all (pixel, splat) pairs from bf16 matrix-core
                                       tiles (gsr_composite_tiles.hip, exact split evaluation) instead of computing them per pair on the
                                       vector ALUs (gsr_composite.hip).  Forward and backward of one view must agree on it. */
+#define GSR_FLAG_NO_COLOR_GRAD 256u /* gsr_backward: the caller does not need dL_dcolors (stage 2: the colours are input pixels, which
+                                       train_stage2.py never differentiates; torch: colors_precomp.requires_grad is False).  The tile family then
+                                       leaves the three colour sums per (pixel, splat) out; dL_dcolors is written as zeros, every other gradient is
+                                       bit-identical.  The VALU family ignores the flag (computes everything). */
 #define GSR_FLAG_TIMING_STAGE(k) (GSR_FLAG_TIMING | (((unsigned)(k) + 1u) << 4)) /* ... or only stage k (GSR_STAGE_*) */
 
 /* stage ids reported by gsr_timing_read() */

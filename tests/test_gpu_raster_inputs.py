@@ -146,3 +146,33 @@ def test_render_batch_with_samples_of_very_different_size(monkeypatch):
     for v in ("lmain", "rmain"):
         for k in keys:
             assert torch.equal(out["batch"][1][v][k], out["literal"][1][v][k]), (v, k)
+
+
+@pytest.mark.parametrize("bg", [(0.0, 0.0, 0.0), (0.3, 0.1, 0.2)], ids=["black", "colour"])
+def test_backward_without_the_colour_gradient(family, bg):
+    """Stage 2 never differentiates the colours (input pixels: colors_precomp.requires_grad is False in the reference's training loop).
+    The autograd module then asks the backward to leave the colour sums out (GSR_FLAG_NO_COLOR_GRAD): every other gradient must be
+    bit-identical to the full backward, the colours get no gradient."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_scene(256, 30000, render_res=512)
+    g["bg"] = np.asarray(bg, np.float32)
+    dpix = np.random.default_rng(9).standard_normal((3, 512, 512)).astype(np.float32)
+    _, _, full, _ = hip_render(g, dpix)
+    dev = torch.device("cuda:0")
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    t = {k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32)).to(dev).requires_grad_(k != "colors") for k in names}
+    m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+    rs = RZ.GaussianRasterizationSettings(g["H"], g["W"], g["tanfovx"], g["tanfovy"], torch.from_numpy(g["bg"]).to(dev), 1.0,
+                                          torch.from_numpy(g["view"]).to(dev), torch.from_numpy(g["proj"]).to(dev), 3,
+                                          torch.from_numpy(g["campos"]).to(dev), False, False)
+    img, _ = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"],
+                                       scales=t["scales"], rotations=t["rotations"])
+    assert img.grad_fn.color_grad is False
+    img.backward(torch.from_numpy(dpix).to(dev))
+    assert t["colors"].grad is None
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        np.testing.assert_array_equal(t[k].grad.cpu().numpy(), full[k], err_msg=k)
+    np.testing.assert_array_equal(m2.grad.cpu().numpy(), full["means2D"])
+    assert np.abs(full["colors"]).max() > 0
