@@ -370,9 +370,19 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     _capi.timing_read()  # drop the warm-up records
-    for _ in range(max(5, min(20, args.steps))):
-        step()
-    stages = _capi.timing_read()
+    # three calibration blocks; per stage the block with the smallest average is kept (one launch that meets a clock ramp or a page fault
+    # -- seen once: a 4.7 ms k_preprocess launch -- would otherwise decide which kernel is called dominant)
+    stages = None
+    for _ in range(3):
+        for _ in range(max(5, min(20, args.steps))):
+            step()
+        blk = _capi.timing_read()
+        if stages is None:
+            stages = blk
+        else:
+            for k_, (ms_, n_) in blk.items():
+                if n_ and (not stages[k_][1] or ms_ / n_ < stages[k_][0] / stages[k_][1]):
+                    stages[k_] = (ms_, n_)
     dom_stage = max(stages, key=lambda k: (stages[k][0] / stages[k][1]) if stages[k][1] else 0.0)
 
     # ---- the timed region.  Only the dominant kernel keeps its hipEvent bracket (on the launch stream), so that the measurement does

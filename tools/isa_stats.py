@@ -13,7 +13,7 @@ path = src if os.path.exists(src) else os.path.join(ROOT, "gps-gaussian_amd", "c
 unit = os.path.basename(path)
 flags = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 if unit in ("gsr_preprocess.hip",): flags += ["-ffp-contract=off", "-fno-slp-vectorize"]
-if unit in ("corr_sampler.hip", "pack_views.hip", "unproject.hip"): flags += ["-ffp-contract=off"]
+if unit in ("corr_sampler.hip", "pack_views.hip", "unproject.hip", "gsr_binning.hip"): flags += ["-ffp-contract=off"]
 if unit.startswith("gsr_composite"): flags += ["-fno-slp-vectorize"]
 out = "/tmp/isa_%s.s" % unit
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *flags, *extra, "-S", "--cuda-device-only", "-o", out, path], check=True, stderr=subprocess.DEVNULL)
