@@ -231,6 +231,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, const uint32
         uint32_t row0;
         gsr_view_rows(row_range, P, row0, P);  // with a row range P was only the capacity: records behind the view's last Gaussian were never written
     }
+    if ((int)(blockIdx.x * GSR_BIN_THREADS) >= P) return;  // workgroup entirely behind the view's last Gaussian (before any barrier: uniform)
     uint32_t lo = 0, hi = 0, mask = 0;
     uint64_t key = 0;
     GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};

@@ -104,6 +104,17 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
         hdr->num_points = m;
         if (m > (uint32_t)q.P) hdr->row_overflow = 1u;  // more rows than the capacity the call was sized for: k_scan_b reports an overflow
     }
+    if ((int)(blockIdx.x * GSR_BIN_THREADS) >= nP && nP < q.P) {
+        // a row-range view is launched for its CAPACITY: a workgroup entirely behind the view's last Gaussian only leaves the neutral
+        // entries the later kernels expect (slot prefix 0, empty bin box, empty masks) -- no barriers, no binning pass
+        if (q.goff) {
+            if (i < q.P) q.goff[i] = 0u;
+            if (threadIdx.x == 0) q.gpart[blockIdx.x] = 0u;
+        }
+        if (i < q.P) hitmask[i] = 0u;
+        if (threadIdx.x < 4) wg_tab[(size_t)blockIdx.x * GSR_WG_TAB_WORDS + threadIdx.x] = 0u;
+        return;
+    }
     if (i < nP) {
     const size_t r = (size_t)row0 + (size_t)i;
     const Cam cam = load_cam(q.view, q.proj);
