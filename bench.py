@@ -130,13 +130,17 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
                         L[kind].backward(L["gout"])
             k -= m
 
-    out = {"P": int(lanes[0]["a"][0].shape[0]), "render": "%dx%d" % (render_res, render_res), "steps": steps}
+    out = {"P": int(lanes[0]["a"][0].shape[0]), "render": "%dx%d" % (render_res, render_res), "steps": steps, "blocks": 3}
     for kind, label in (("train", "fwd_bwd"), ("infer", "fwd_only")):
         out[label] = {}
         for n, nl in ((1, "one_view_in_flight"), (inflight, "%d_views_in_flight" % inflight)):
             run(kind, n, 2 * n + 3)  # warm-up: capacities learnt, workspaces allocated
-            el = timed(lambda k, kind=kind, n=n: run(kind, n, k), steps, 0, multi=True)
-            out[label][nl] = {"views_per_s": round(steps / el, 1), "ms_per_view": round(el / steps * 1e3, 4)}
+            allocs0 = sum(L[kind].allocations for L in lanes)
+            els = sorted(timed(lambda k, kind=kind, n=n: run(kind, n, k), steps, 0, multi=True) for _ in range(3))  # three blocks of `steps` steps
+            el = els[1]
+            out[label][nl] = {"views_per_s": round(steps / el, 1), "ms_per_view": round(el / steps * 1e3, 4),
+                              "blocks_ms_per_view": [round(x / steps * 1e3, 4) for x in els],
+                              "workspace_reallocations_while_timed": sum(L[kind].allocations for L in lanes) - allocs0}
     out["R"] = int(RZ.last_stats(dev).get("last_R", 0))
     return out
 

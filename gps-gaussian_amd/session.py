@@ -31,6 +31,7 @@ class RasterSession:
         self.color = torch.empty((3, self.H, self.W), dtype=f32, device=d)
         self.radii = torch.empty((self.P,), dtype=torch.int32, device=d)
         self.ws, self.cap, self.nbytes = None, 0, 0
+        self.allocations = 0  # workspace (re)allocations so far: 1 in steady state
         self._in, self._pending, self._cur = None, None, None
         if self.training:
             # one buffer, six contiguous gradient arrays carved out of it
@@ -48,6 +49,7 @@ class RasterSession:
             self.nbytes = self._ws_bytes(self.P, self.W, self.H, cap)
             self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=self.dev)
             self.cap = cap
+            self.allocations += 1
 
     @staticmethod
     def _chk(t, n, name):

@@ -101,6 +101,70 @@ int main() {
             GPSGS_E_INVALID) { printf("notify_seq 0 was accepted\n"); return 1; }
         CK(hipHostFree((void *)pin));
     }
+    // ABI version 2: the same view as a ROW RANGE of batch-wide arrays (what a pts2render-style caller has after packing a batch): the
+    // Gaussians sit in rows [P, 2P) of arrays of 3P rows whose other rows hold NaNs, {begin, end} lives in device memory, the call is sized
+    // for a capacity of P + 100 rows.  Image and gradients must equal the plain call bit for bit; without the colour gradient
+    // (GSR_FLAG_NO_COLOR_GRAD) every other gradient must still be identical and dL_dcolors must be zero.
+    {
+        if (gpsgs_abi_version() != 2) { printf("ABI version %d\n", gpsgs_abi_version()); return 1; }
+        const float nanv = std::nanf("");
+        auto wide = [&](const std::vector<float> &src, int ch) {
+            std::vector<float> w((size_t)3 * P * ch, nanv);
+            for (size_t k = 0; k < (size_t)P * ch; k++) w[(size_t)P * ch + k] = src[k];
+            return w;
+        };
+        float *wm = dev(wide(m, 3)), *wc = dev(wide(c, 3)), *wo = dev(wide(o, 1)), *wsc = dev(wide(s, 3)), *wr = dev(wide(r, 4));
+        std::vector<uint32_t> range = {(uint32_t)P, (uint32_t)(2 * P)};
+        uint32_t *drange = dev(range);
+        const int Pcap = P + 100;
+        const size_t nb2 = gsr_workspace_bytes(Pcap, W, H, cap);
+        void *ws2; float *color2; int *radii2;
+        CK(hipMalloc(&ws2, nb2)); CK(hipMalloc(&color2, sizeof(float) * 3 * W * H)); CK(hipMalloc(&radii2, sizeof(int) * 3 * P));
+        // the plain calls once more with the default kernel family (exponents from the matrix-core tiles): the comparison baseline
+        const unsigned TF = GSR_FLAG_COMPOSITE_TILES;
+        rc = gsr_forward(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color, radii, ws, nbytes, cap, TF, st);
+        if (rc == GPSGS_OK) rc = gsr_backward(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, radii, dgp, g3, g2, gc, go, gs, gr, ws, nbytes, cap, TF, st);
+        if (rc != GPSGS_OK) { printf("tile-family baseline rc=%d\n", rc); return 1; }
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(img.data(), color, img.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hgc.data(), gc, 12 * P, hipMemcpyDeviceToHost));
+        GsrViewExt ext = {};
+        ext.row_range = drange;
+        ext.order_hint = h.max_tile_count;
+        rc = gsr_forward_ex(Pcap, W, H, wm, wc, wo, wsc, wr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color2, radii2, ws2, nb2, cap, TF, st, nullptr, 0u, &ext);
+        if (rc != GPSGS_OK) { printf("gsr_forward_ex rc=%d\n", rc); return 1; }
+        GsrHeader h2;
+        if (gsr_read_header(ws2, &h2, st) != GPSGS_OK) return 1;
+        if (h2.overflow || h2.num_rendered != h.num_rendered || h2.num_points != (uint32_t)P || h2.row_overflow) {
+            printf("row-range header: overflow=%u R=%llu points=%u\n", h2.overflow, (unsigned long long)h2.num_rendered, h2.num_points); return 1;
+        }
+        std::vector<float> img2(3 * W * H);
+        CK(hipMemcpy(img2.data(), color2, img2.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < img.size(); k++) if (img2[k] != img[k]) { printf("row-range image differs at %zu\n", k); return 1; }
+        float *w3, *w2, *wgc, *wgo, *wgs, *wgr;
+        CK(hipMalloc(&w3, 36 * P)); CK(hipMalloc(&w2, 36 * P)); CK(hipMalloc(&wgc, 36 * P)); CK(hipMalloc(&wgo, 12 * P)); CK(hipMalloc(&wgs, 36 * P)); CK(hipMalloc(&wgr, 48 * P));
+        for (int pass = 0; pass < 2; pass++) {  // 0: all gradients, 1: without the colour gradient
+            rc = gsr_backward_ex(Pcap, W, H, wm, wc, wo, wsc, wr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, radii2, dgp, w3, w2, wgc, wgo, wgs, wgr, ws2, nb2, cap,
+                                 TF | (pass ? GSR_FLAG_NO_COLOR_GRAD : 0u), st, &ext);
+            if (rc != GPSGS_OK) { printf("gsr_backward_ex rc=%d\n", rc); return 1; }
+            CK(hipStreamSynchronize(st));
+            std::vector<float> a(3 * P), b(3 * P), col(3 * P);
+            CK(hipMemcpy(a.data(), g3, 12 * P, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), w3 + 3 * P, 12 * P, hipMemcpyDeviceToHost));   // rows [P, 2P) of the batch-wide gradient array
+            CK(hipMemcpy(col.data(), wgc + 3 * P, 12 * P, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 3 * P; k++) {
+                if (a[k] != b[k]) { printf("row-range dL_dmeans3D differs at %d (pass %d)\n", k, pass); return 1; }
+                if (pass == 0 ? col[k] != hgc[k] : col[k] != 0.f) { printf("row-range dL_dcolors wrong at %d (pass %d)\n", k, pass); return 1; }
+            }
+        }
+        // a range longer than the capacity is reported like an overflow
+        std::vector<uint32_t> big = {0u, (uint32_t)(3 * P)};
+        uint32_t *dbig = dev(big);
+        ext.row_range = dbig;
+        rc = gsr_forward_ex(Pcap, W, H, wm, wc, wo, wsc, wr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color2, radii2, ws2, nb2, cap, TF, st, nullptr, 0u, &ext);
+        if (rc != GPSGS_OK || gsr_read_header(ws2, &h2, st) != GPSGS_OK) return 1;
+        if (!h2.overflow || !h2.row_overflow || h2.num_points != (uint32_t)(3 * P)) { printf("row overflow not reported\n"); return 1; }
+    }
     // argument checking happens before any launch
     if (gsr_forward(P, 0, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, nbytes, cap, 0, st) != GPSGS_E_INVALID) return 1;
     if (gsr_forward(P, W, H, dm, dc, dop, ds, dr, 1.f, 1.f, 1.f, dv, dp, dbg, color, radii, ws, 64, cap, 0, st) != GPSGS_E_WORKSPACE) return 1;
