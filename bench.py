@@ -348,6 +348,8 @@ def main():
     def barrier():
         D.barrier(local_rank)
 
+    import gc
+
     def timed(fn, steps, warmup, multi=False):  # multi: fn(k) runs k steps itself (pipelined groups)
         if multi:
             fn(warmup)
@@ -355,18 +357,26 @@ def main():
             for _ in range(warmup):
                 fn()
         torch.cuda.synchronize(dev)
-        barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        if multi:
-            fn(steps)
-        else:
-            for _ in range(steps):
-                fn()
-        torch.cuda.synchronize(dev)
-        barrier()
-        torch.cuda.synchronize(dev)
-        return D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        # the host's cyclic garbage collector stays out of the timed region (a full collection of a process that has imported torch takes
+        # tens of milliseconds -- the size of the rare outlier blocks seen in the 2048^2 legs -- against timed blocks of 5-50 ms)
+        gc.collect()
+        gc.disable()
+        try:
+            barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            if multi:
+                fn(steps)
+            else:
+                for _ in range(steps):
+                    fn()
+            torch.cuda.synchronize(dev)
+            barrier()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        return D.max_over_ranks(el, device=dev)
 
     # ---- calibration (untimed): every kernel bracketed by hipEvents -> per-stage table, dominant kernel ------------------
     RZ.set_stage_timing(True)

@@ -74,7 +74,7 @@ def main():
     torch.cuda.synchronize()
     total = time.perf_counter() - t_all
     d = np.array([r[0] for r in rec]) * 1e3
-    slow = [(i, round(float(d[i]), 3), rec[i][1], rec[i][2], rec[i][3]) for i in np.argsort(d)[::-1][:8]]
+    slow = [(int(i), round(float(d[i]), 3), int(rec[i][1]), bool(rec[i][2]), int(rec[i][3])) for i in np.argsort(d)[::-1][:8]]
     print(json.dumps({"workload": "%dx%d P=%d %s, %d in flight" % (rr, rr, lanes[0]["a"][0].shape[0], args.kind, args.inflight), "groups": len(rec),
                       "ms_per_group": {"median": round(float(np.median(d)), 4), "p99": round(float(np.quantile(d, 0.99)), 4), "max": round(float(d.max()), 3)},
                       "views_per_s_overall": round(len(rec) * args.inflight / total, 1),
