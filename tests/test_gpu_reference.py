@@ -275,8 +275,11 @@ def test_launcher_world_1_with_the_real_networks(tmp_path):
     work = refenv.make_workdir(REF, str(tmp_path / "w"), {"stage1_ckpt": "None", "dataset": {"src_res": 256, "data_root": data_root}})
     tfile = str(tmp_path / "timing.json")
     res = _tool([os.path.join(ROOT, "tools", "launch_stage2.py"), "--reference", REF, "--workdir", work, "--steps", "5", "--exp-root", str(tmp_path / "exp"),
-                 "--timing", tfile, "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", "1000"], env={"MASTER_ADDR": "127.0.0.1"})
-    assert res["world_size"] == 1 and res["steps"] == 5
+                 "--timing", tfile, "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", "1000"],
+                env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29553", "GPSGS_DIST_FORCE": "1"})
+    # GPSGS_DIST_FORCE=1: the process group is initialised (backend nccl = RCCL) and the exchange step -- the mean all-reduce of all 5,144,408
+    # gradients hooked into GradScaler.unscale_ -- is ISSUED at world size 1: RCCL runs inside the reference's own training loop
+    assert res["world_size"] == 1 and res["steps"] == 5 and res["backend"] == "nccl", res
     t = json.load(open(tfile))
     for k in ("network_forward", "pts2render", "loss_l1", "loss_ssim", "backward", "optimizer_step"):
         assert len(t[k]) == 5 and min(t[k]) > 0, (k, t[k])
