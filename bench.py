@@ -121,13 +121,11 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         while k > 0:
             m = min(n, k)
             for L in lanes[:m]:
-                with torch.cuda.stream(L["stream"]):
-                    L[kind].forward_begin(*L["a"])
+                L[kind].forward_begin(*L["a"], L["stream"])
             for L in lanes[:m]:
-                with torch.cuda.stream(L["stream"]):
-                    L[kind].forward_end()
-                    if kind == "train":
-                        L[kind].backward(L["gout"])
+                L[kind].forward_end()
+                if kind == "train":
+                    L[kind].backward(L["gout"], stream=L["stream"])
             k -= m
 
     out = {"P": int(lanes[0]["a"][0].shape[0]), "render": "%dx%d" % (render_res, render_res), "steps": steps, "blocks": 3}
@@ -310,14 +308,12 @@ def main():
                           proj=torch.from_numpy(ci["full_proj_transform"]).to(dev), gout=torch.randn(3, H, W, device=dev)))
     torch.cuda.synchronize(dev)
 
-    def group(n):  # n <= F views, concurrently
+    def group(n):  # n <= F views, concurrently (every session is handed its stream: PyTorch's current stream is never switched)
         for L in lanes[:n]:
-            with torch.cuda.stream(L["stream"]):
-                L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
+            L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0, L["stream"])
         for L in lanes[:n]:
-            with torch.cuda.stream(L["stream"]):
-                L["sess"].forward_end()
-                L["sess"].backward(L["gout"])
+            L["sess"].forward_end()
+            L["sess"].backward(L["gout"], stream=L["stream"])
 
     def steps_pipelined(k):
         while k > 0:
@@ -326,12 +322,10 @@ def main():
 
     def group_s2(n):  # the same with the gradient set stage 2 needs: no dL/dcolour (the colours are input pixels, never differentiated)
         for L in lanes[:n]:
-            with torch.cuda.stream(L["stream"]):
-                L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
+            L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0, L["stream"])
         for L in lanes[:n]:
-            with torch.cuda.stream(L["stream"]):
-                L["sess"].forward_end()
-                L["sess"].backward(L["gout"], color_grad=False)
+            L["sess"].forward_end()
+            L["sess"].backward(L["gout"], color_grad=False, stream=L["stream"])
 
     def steps_pipelined_s2(k):
         while k > 0:
