@@ -342,7 +342,14 @@ def main():
     def barrier():
         D.barrier(local_rank)
 
+    # The host's cyclic garbage collector is switched off for the whole measurement (one collection + freeze first): a full collection of a
+    # process that has imported torch takes tens of milliseconds -- the size of the rare outlier blocks seen in the 2048^2 legs -- against
+    # timed blocks of 5-50 ms.  (Collecting before every timed block instead leaves the GPU idle for those milliseconds right before the
+    # clock starts: its clocks drop and EVERY block reads 10-15 % slower -- measured.)
     import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 
     def timed(fn, steps, warmup, multi=False):  # multi: fn(k) runs k steps itself (pipelined groups)
         if multi:
@@ -351,26 +358,18 @@ def main():
             for _ in range(warmup):
                 fn()
         torch.cuda.synchronize(dev)
-        # the host's cyclic garbage collector stays out of the timed region (a full collection of a process that has imported torch takes
-        # tens of milliseconds -- the size of the rare outlier blocks seen in the 2048^2 legs -- against timed blocks of 5-50 ms)
-        gc.collect()
-        gc.disable()
-        try:
-            barrier()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            if multi:
-                fn(steps)
-            else:
-                for _ in range(steps):
-                    fn()
-            torch.cuda.synchronize(dev)
-            barrier()
-            torch.cuda.synchronize(dev)
-            el = time.perf_counter() - t0
-        finally:
-            gc.enable()
-        return D.max_over_ranks(el, device=dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        if multi:
+            fn(steps)
+        else:
+            for _ in range(steps):
+                fn()
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        return D.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     # ---- calibration (untimed): every kernel bracketed by hipEvents -> per-stage table, dominant kernel ------------------
     RZ.set_stage_timing(True)
