@@ -441,8 +441,11 @@ __global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ b
     else sort_wave_regs<16>(seg, n, out, lane);
 }
 
-// lists longer than 1024 keys are rare: a small persistent grid (64) of 1024-thread workgroups (128 KiB LDS each) strides
-// over the bins and picks them up (launching one big workgroup per bin just to exit cost ~18 us at 16,384 bins)
+// lists longer than 1024 keys: a persistent grid of 1024-thread workgroups (128 KiB LDS each: one resident per CU) strides over the bins
+// and picks them up (launching one big workgroup per bin just to exit cost ~18 us at 16,384 bins).  Rare in the synthetic configs (the
+// launch is left out until a long list has been seen on the device), the NORM with freshly initialised networks: BASELINE config 3 with random
+// weights has ~20,000 bins of 1,000-3,000 entries per view, and the 64-workgroup grid of rounds 1-2 took 6.0 ms of a 7.6 ms render there
+// (profiles/r03_config3_kernel_stats.md) -- hence up to 1,024 workgroups: every CU busy, and the stride spreads long and short lists
 __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
                                                      uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
     __shared__ uint64_t sk[16384];
@@ -485,5 +488,5 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
     if (NB <= 0) return;
     hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     if (no_large_sort) return;  // the scan has turned any list longer than 1024 into an overflow (nothing downstream runs)
-    hipLaunchKernelGGL(k_sort_large, dim3(NB < 64 ? NB : 64), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_large, dim3(NB < 1024 ? NB : 1024), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }
