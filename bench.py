@@ -121,6 +121,7 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         while k > 0:
             m = min(n, k)
             for L in lanes[:m]:
+                L[kind].wave_priority = n == 1
                 L[kind].forward_begin(*L["a"], L["stream"])
             for L in lanes[:m]:
                 L[kind].forward_end()
@@ -310,6 +311,7 @@ def main():
 
     def group(n):  # n <= F views, concurrently (every session is handed its stream: PyTorch's current stream is never switched)
         for L in lanes[:n]:
+            L["sess"].wave_priority = n == 1  # GSR_FLAG_WAVE_PRIORITY pays for a view that has the chip to itself, costs ~2 % of the aggregate with views overlapped
             L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0, L["stream"])
         for L in lanes[:n]:
             L["sess"].forward_end()
@@ -322,6 +324,7 @@ def main():
 
     def group_s2(n):  # the same with the gradient set stage 2 needs: no dL/dcolour (the colours are input pixels, never differentiated)
         for L in lanes[:n]:
+            L["sess"].wave_priority = n == 1
             L["sess"].forward_begin(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0, L["stream"])
         for L in lanes[:n]:
             L["sess"].forward_end()
@@ -628,6 +631,9 @@ def main():
                                "autograd round trip; the same step through the drop-in autograd module is `autograd_api_views_per_s`",
                        "views_in_flight": "%d independent views per GPU rendered concurrently (one session + HIP stream each); one at a time: "
                                           "`single_view_in_flight_views_per_s`" % F,
+                       "wave_priority": "GSR_FLAG_WAVE_PRIORITY (hardware wave priorities in the compositing kernels, results unchanged) is ON for every "
+                                        "one-view-at-a-time measurement (single_view_in_flight, autograd_api, stages, roofline) and OFF while several views "
+                                        "are in flight (`value`): measured best for each mode",
                        "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)"},
             "repeats_ms_per_step": [round(x / args.steps * 1e3, 4) for x in blocks],
             "ms_per_step_iqr": [round(q1 / args.steps * 1e3, 4), round(q3 / args.steps * 1e3, 4)],

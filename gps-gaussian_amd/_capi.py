@@ -21,6 +21,7 @@ GSR_FLAG_NO_LARGE_SORT = 4
 GSR_FLAG_TIMING = 2
 GSR_FLAG_COMPOSITE_TILES = 8
 GSR_FLAG_NO_COLOR_GRAD = 256
+GSR_FLAG_WAVE_PRIORITY = 512
 STAGES = ("preprocess", "scan", "scatter", "sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 
 

@@ -228,7 +228,7 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
         trace("composite_fwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
         if (flags & GSR_FLAG_COMPOSITE_TILES)
-            gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, training, s);
+            gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, training, (flags & GSR_FLAG_WAVE_PRIORITY) != 0, s);
         else
             gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
     }
@@ -289,7 +289,7 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
         // backward has to repeat the forward's per-pixel decisions
         if (flags & GSR_FLAG_COMPOSITE_TILES)
             gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr,
-                                           (flags & GSR_FLAG_NO_COLOR_GRAD) == 0, s);
+                                           (flags & GSR_FLAG_NO_COLOR_GRAD) == 0, (flags & GSR_FLAG_WAVE_PRIORITY) != 0, s);
         else
             gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
     }

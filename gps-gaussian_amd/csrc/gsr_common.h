@@ -353,12 +353,14 @@ static inline unsigned gsr_debug_lds_pad() {
 // exponents from bf16 matrix-core tiles (gsr_composite_tiles.hip): same arguments, same results within rounding
 void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr,
-                                    bool keep_state /* false: inference workspace, final_T / n_contrib are not produced */, hipStream_t s);
+                                    bool keep_state /* false: inference workspace, final_T / n_contrib are not produced */,
+                                    bool wave_prio /* GSR_FLAG_WAVE_PRIORITY */, hipStream_t s);
 int gsr_set_wg_trace(unsigned long long *rows_device);  // development aid: per-workgroup timeline of the tile compositing kernels (NULL = off)
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
                                     const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop, GsrGradAcc *inst_grad, const GsrHeader *hdr,
-                                    bool color_grad /* false: GSR_FLAG_NO_COLOR_GRAD, the colour sums are left out (zeros in the records) */, hipStream_t s);
+                                    bool color_grad /* false: GSR_FLAG_NO_COLOR_GRAD, the colour sums are left out (zeros in the records) */,
+                                    bool wave_prio /* GSR_FLAG_WAVE_PRIORITY */, hipStream_t s);
 void gsr_launch_selftest(float *out4, hipStream_t s);
 struct GsrBwdParams {
     int P, W, H;

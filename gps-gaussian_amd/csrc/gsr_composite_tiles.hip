@@ -40,6 +40,28 @@ struct WgTrace {
     }
 };
 
+// GSR_FLAG_WAVE_PRIORITY -- hardware wave priority (s_setprio, 0..3) as a scheduling hint; results are unchanged.  A SIMD's arbiter serves
+// the highest priority first and the OLDEST wave among equals.  Config 2 has ~5 busy bins (= one-wave workgroups of ~370 list entries)
+// per SIMD and a wave on its own is latency-bound (per-workgroup timeline, occupancy sweep, issue probes):
+//   forward: all of a SIMD's waves are resident from the start; served oldest first they finish one after the other (40, 43, 48, 53,
+//     59 us on one SIMD with five equal lists) and the last one runs alone.  With the priority following the work a wave still has in
+//     front of it, relative to the longest list of the view, they finish together and the SIMD stays full to the end;
+//   backward: three waves fit per SIMD, the fourth and fifth workgroup start when a slot frees up, next to first-generation waves that
+//     are almost done.  Late starters go first: the last three waves of a SIMD then finish together instead of the late starters being
+//     what the launch ends on.  (Equalising the first generation as in the forward is worse here: all three slots would free up at once
+//     and the second generation would run two-wide.)
+__device__ __forceinline__ void prio_by_remaining(uint32_t rem, uint32_t longest) {
+    const uint32_t r4 = 4u * rem;  // wave-uniform: scalar compares and branches
+    if (r4 >= 3u * longest) __builtin_amdgcn_s_setprio(3);
+    else if (r4 >= 2u * longest) __builtin_amdgcn_s_setprio(2);
+    else if (r4 >= longest) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void prio_late_starter(uint32_t rem, uint32_t longest) {  // 3 while more than half of the longest list is left, then 2
+    if (4u * rem >= 2u * longest) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(2);
+}
+
 struct TileFwdState {
     float T, C0, C1, C2;
     uint32_t last_rnd;
@@ -80,6 +102,15 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
                 st.C2 += c.w * w;
                 st.T = T_next;
                 if (KEEP) st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
+#ifdef GSR_ABL_VALU  // issue probes (tools/gpu_r03_n.sh; never defined in a product build): extra work per pair that changes no result
+                { float d0_, d1_; __asm__ volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %2, %2" : "=v"(d0_), "=v"(d1_) : "v"(c.y)); }
+#endif
+#ifdef GSR_ABL_SALU
+                { uint32_t sd_ = 0; __asm__ volatile("s_xor_b32 %0, %0, 1\n\ts_xor_b32 %0, %0, 3" : "+s"(sd_) : : "scc"); }
+#endif
+#ifdef GSR_ABL_EXP
+                { float d0_; __asm__ volatile("v_exp_f32 %0, %1" : "=v"(d0_) : "v"(c.y)); }
+#endif
             }
         }
     }
@@ -90,7 +121,7 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             float *__restrict__ out_color, float *__restrict__ final_T,
-                                                            uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr) {
+                                                            uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr, int wave_prio) {
     __shared__ float4 sCol[WAVE];  // {opacity, r, g, b} of the 64 staged splats
     const WgTrace trace(blockIdx.x);
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
@@ -118,6 +149,7 @@ __global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int
     }
     for (uint32_t base = r0; base < r1; base += WAVE) {
         if (st.active == 0ull) break;  // every pixel of this bin is saturated (or outside the image)
+        if (wave_prio) prio_by_remaining(r1 - base, hdr->max_tile_count);
         const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy, gsr_log2_opacity(nB.y)));
         wave_sync_lds();  // previous round fully consumed
         sCol[lane] = make_float4(nB.y, nB.z, nB.w, nC);
@@ -249,6 +281,15 @@ __device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdCo
         st.A = __builtin_fmaf(ae, cA, st.A);  // = ae cd + (1 - ae) A
         k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
         if (CG) k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
+#ifdef GSR_ABL_BVALU  // issue probes (never defined in a product build)
+        { float d0_, d1_; __asm__ volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %2, %2" : "=v"(d0_), "=v"(d1_) : "v"(c.x)); }
+#endif
+#ifdef GSR_ABL_BSALU
+        { uint32_t sd_ = 0; __asm__ volatile("s_xor_b32 %0, %0, 1\n\ts_xor_b32 %0, %0, 3" : "+s"(sd_) : : "scc"); }
+#endif
+#ifdef GSR_ABL_BEXP
+        { float d0_; __asm__ volatile("v_exp_f32 %0, %1" : "=v"(d0_) : "v"(c.x)); }
+#endif
     }
 }
 
@@ -283,7 +324,7 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
                                                             const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
                                                             const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid, float *__restrict__ inst_dop,
                                                             GsrGradAcc *__restrict__ inst_grad,
-                                                            const GsrHeader *__restrict__ hdr) {
+                                                            const GsrHeader *__restrict__ hdr, uint32_t prio_from_wg) {
     __shared__ float4 sXY[WAVE];       // {x, y, A, B} of the staged splats (x, y for the moments; A, B for the flush)
     __shared__ float4 sCol[WAVE];      // {r, g, b, -}: colour first, so that one aligned ds_read_b96 (immediate offset) fetches it
     __shared__ float4 sAcc[WAVE * 3];  // per staged splat: {dr,dg,db,Sx | Sy,Sxx,Sxy,Syy | 4 partial sums of S0}
@@ -374,6 +415,8 @@ __global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int
     for (int64_t top = max_last - 1; top >= 0; top -= WAVE) {
         const int cnt = (int)min((int64_t)WAVE, top + 1);
         const uint32_t topu = (uint32_t)top;
+        // GSR_FLAG_WAVE_PRIORITY: workgroups behind the first resident generation (prio_from_wg = what the chip holds at once; 0 = off)
+        if (prio_from_wg && blockIdx.x >= prio_from_wg) prio_late_starter(topu + 1u, hdr->max_tile_count);
         const PowOperandsA opA = pow_operands_a(pow_terms(nA.x, nA.y, nA.z, nA.w, nB.x, cx, cy, gsr_log2_opacity(nB.y)));
         wave_sync_lds();  // previous round fully consumed
         sXY[lane] = nA;
@@ -480,29 +523,42 @@ __global__ __launch_bounds__(64) void k_selftest_tiles(float *__restrict__ out) 
 
 void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
-                                    const GsrHeader *hdr, bool keep_state, hipStream_t s) {
+                                    const GsrHeader *hdr, bool keep_state, bool wave_prio, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
     if (keep_state)
         hipLaunchKernelGGL(k_composite_fwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list,
-                           bg, out_color, final_T, n_contrib, hdr);
+                           bg, out_color, final_T, n_contrib, hdr, wave_prio ? 1 : 0);
     else
         hipLaunchKernelGGL(k_composite_fwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list,
-                           bg, out_color, final_T, n_contrib, hdr);
+                           bg, out_color, final_T, n_contrib, hdr, wave_prio ? 1 : 0);
 }
 
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
                                     const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop,
-                                    GsrGradAcc *inst_grad, const GsrHeader *hdr, bool color_grad, hipStream_t s) {
+                                    GsrGradAcc *inst_grad, const GsrHeader *hdr, bool color_grad, bool wave_prio, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
+    // workgroups the chip holds at once (the first generation), per kernel instantiation: occupancy x compute units, asked once
+    static uint32_t resident[2] = {0u, 0u};
+    uint32_t &res = resident[color_grad ? 1 : 0];
+    if (wave_prio && res == 0u) {
+        int per_cu = 0, dev = 0, cus = 0;
+        const void *fn = color_grad ? reinterpret_cast<const void *>(k_composite_bwd_tiles<true>) : reinterpret_cast<const void *>(k_composite_bwd_tiles<false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, gsr_debug_lds_pad()) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+            res = (uint32_t)per_cu * (uint32_t)cus;
+        else
+            res = 0xffffffffu;  // unknown: no workgroup counts as a late starter
+    }
+    const uint32_t prio_from_wg = wave_prio ? res : 0u;
     if (color_grad)
         hipLaunchKernelGGL(k_composite_bwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
-                           dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+                           dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr, prio_from_wg);
     else
         hipLaunchKernelGGL(k_composite_bwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
-                           dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+                           dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr, prio_from_wg);
 }
 
 int gsr_set_wg_trace(unsigned long long *rows_device) {

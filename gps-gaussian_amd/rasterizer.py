@@ -97,6 +97,12 @@ def _composite_flag():
 _DEFAULT_FAMILY = "tiles"
 
 
+def _wave_priority_flag():
+    """GSR_FLAG_WAVE_PRIORITY unless GPSGS_WAVE_PRIORITY=0 (include/gpsgs.h: hardware wave priorities in the tile compositing kernels; results
+    unchanged)."""
+    return 0 if os.environ.get("GPSGS_WAVE_PRIORITY", "1") == "0" else _capi.GSR_FLAG_WAVE_PRIORITY
+
+
 def _check_mode():
     m = os.environ.get("GPSGS_CHECK", "sync")
     if m not in ("sync", "deferred", "none"):
@@ -359,7 +365,9 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
     view = _cam(rs.viewmatrix, 16, dev)
     proj = _cam(rs.projmatrix, 16, dev)
     bg = _cam(rs.bg, 3, dev)
-    family = _composite_flag()
+    # the compositing family and, for a view rendered on its own (the GaussianRasterizer module: no row range), the wave-priority scheme --
+    # it pays when the view's kernels have the chip to themselves; a batch spreads its views over several streams and leaves it off
+    family = _composite_flag() | (_wave_priority_flag() if rows is None else 0)
     extra = _extra_flags  # read ONCE per view and carried to its backward in ctx (the backward runs on an autograd thread)
     base_flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | extra | family
     mode = _check_mode()

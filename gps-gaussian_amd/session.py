@@ -20,12 +20,15 @@ from . import rasterizer as RZ
 
 
 class RasterSession:
-    def __init__(self, P, width, height, device, training=True):
+    def __init__(self, P, width, height, device, training=True, wave_priority=True):
         self.P, self.W, self.H = int(P), int(width), int(height)
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("gps_gaussian_amd: RasterSession needs a GPU device (no CPU path exists)")
         self.training = bool(training)
+        # GSR_FLAG_WAVE_PRIORITY (include/gpsgs.h): on for a session that renders on its own; a caller that keeps several sessions in
+        # flight on different streams passes False (the kernels of different views then share the SIMDs and the scheme costs ~2 %)
+        self.wave_priority = bool(wave_priority)
         self.lib = _capi.lib()
         d, f32 = self.dev, torch.float32
         self.color = torch.empty((3, self.H, self.W), dtype=f32, device=d)
@@ -74,7 +77,7 @@ class RasterSession:
                 self._chk(scales, 3 * P, "scales"), self._chk(rotations, 4 * P, "rotations"))
         cam = (self._chk(viewmatrix, 16, "viewmatrix"), self._chk(projmatrix, 16, "projmatrix"), self._chk(bg, 3, "bg"))
         fl = (float(scale_modifier), float(tanfovx), float(tanfovy))
-        family = RZ._composite_flag()
+        family = RZ._composite_flag() | (RZ._wave_priority_flag() if self.wave_priority else 0)
         self._in = (ptrs, fl, cam, family, (means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg))  # keeps the inputs alive
         st = RZ._dev_state(self.dev)
         self._cur = stream if stream is not None else torch.cuda.current_stream(self.dev)

@@ -64,6 +64,13 @@ enum {
                                        train_stage2.py never differentiates; torch: colors_precomp.requires_grad is False).  The tile family then
                                        leaves the three colour sums per (pixel, splat) out; dL_dcolors is written as zeros, every other gradient is
                                        bit-identical.  The VALU family ignores the flag (computes everything). */
+#define GSR_FLAG_WAVE_PRIORITY 512u /* tile family: the compositing waves set their hardware priority (s_setprio) from the work they still
+                                       have in front of them -- forward: more list left = higher priority, so that the waves resident on a SIMD
+                                       finish together instead of one after the other (the arbiter serves the oldest wave first); backward:
+                                       workgroups dispatched after the first resident generation overtake the leftovers of that generation.
+                                       Results are unchanged.  It pays when a view's kernels have the chip to themselves (measured, config 2:
+                                       forward 55 -> 51 us, backward 114 -> 110 us); with several views' kernels overlapped on other streams it
+                                       costs ~2 % of the aggregate rate, so it is opt-in per call. */
 #define GSR_FLAG_TIMING_STAGE(k) (GSR_FLAG_TIMING | (((unsigned)(k) + 1u) << 4)) /* ... or only stage k (GSR_STAGE_*) */
 
 /* stage ids reported by gsr_timing_read() */

@@ -418,6 +418,24 @@ def test_backward_is_bit_reproducible():
         np.testing.assert_array_equal(g1[k], g2[k])
 
 
+def test_wave_priority_flag_changes_no_bit(monkeypatch):
+    """GSR_FLAG_WAVE_PRIORITY (hardware wave priorities in the tile compositing kernels: a scheduling hint) must not change a single bit of
+    the image, the radii or any gradient -- at config-2 density, where the backward has more workgroups than the chip holds at once (the
+    late-starter rule needs a second generation), and on a small cloud."""
+    from gps_gaussian_amd import synthetic as S
+    monkeypatch.setenv("GPSGS_COMPOSITE", "tiles")
+    for g in (S.make_scene(256, 30000), S.make_scene(1024, 600000)):
+        dpix = np.random.default_rng(3).standard_normal((3, g["H"], g["W"])).astype(np.float32)
+        out = {}
+        for on in ("1", "0"):
+            monkeypatch.setenv("GPSGS_WAVE_PRIORITY", on)
+            out[on] = hip_render(g, dpix)
+        np.testing.assert_array_equal(out["1"][0], out["0"][0])
+        np.testing.assert_array_equal(out["1"][1], out["0"][1])
+        for k in out["1"][2]:
+            np.testing.assert_array_equal(out["1"][2][k], out["0"][2][k])
+
+
 def test_stale_gradient_records_of_an_earlier_view_are_never_read():
     """The per-instance gradient records live in slots that belong to (Gaussian, cell of its bin rect) and are reused from view to
     view; a flag byte per slot -- cleared by k_scatter, set by the compositing backward -- says whether THIS backward wrote the
