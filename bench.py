@@ -544,7 +544,7 @@ def main():
                     "launches_averaged": int(dom_excl[1]) if dom == dom_stage else None,
                     "measured": "hipEvents around the kernel on its launch stream over a timed region of %d steps with ONE view in flight (exclusive "
                                 "duration; profiles/r03_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % n_single,
-                    "bound_note": "the contract's roofline is HBM; this kernel is VALU-issue bound (valu_issue_frac), its HBM fraction is low by construction (DESIGN.md section 4)",
+                    "bound_note": "the contract's roofline is HBM; this kernel's HBM fraction is low by construction (>= 50 op/B).  With a view on its own it is bound by the shape of the work -- 5 one-wave work items of ~370 list entries per SIMD, a lone wave is latency-bound -- not by VALU issue: adding 18 % VALU instructions per pair costs 4 % (profiles/r03_issue_probes.md, DESIGN.md section 4)",
                     # the same kernel inside the headline region: F views in flight, launches of different views overlap and time-share the chip
                     "headline_region": {"views_in_flight": F, "avg_launch_us": ovl_us,
                                         "frac": (round(alg_bytes[dom] / (ovl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if ovl_us else None)},
