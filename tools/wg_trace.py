@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--render-res", type=int, default=None)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "wg_trace.npz"))
     ap.add_argument("--hint", type=int, default=None)
+    ap.add_argument("--no-priority", action="store_true", help="render without GSR_FLAG_WAVE_PRIORITY (the session's default is on)")
     args = ap.parse_args()
     import torch
     import gps_gaussian_amd  # noqa: F401
@@ -101,7 +102,7 @@ def main():
     g, cam = S.compact_sample(smp), smp["novel_view"]
     t = {k: torch.from_numpy(g[k]).to(dev) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     P = t["means3D"].shape[0]
-    sess = RasterSession(P, rr, rr, dev, training=True)
+    sess = RasterSession(P, rr, rr, dev, training=True, wave_priority=not args.no_priority)
     a = (t["means3D"], t["colors"], t["opacities"].reshape(-1), t["scales"], t["rotations"], torch.from_numpy(cam["world_view_transform"]).to(dev),
          torch.from_numpy(cam["full_proj_transform"]).to(dev), torch.zeros(3, device=dev), math.tan(float(cam["FovX"]) * 0.5), math.tan(float(cam["FovY"]) * 0.5), 1.0)
     gout = torch.randn(3, rr, rr, device=dev)
@@ -124,6 +125,7 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     np.savez_compressed(args.out, fwd=h[:NB], bwd=h[NB:])
     out = {"workload": "%dx%d, P=%d, hint=%s" % (rr, rr, P, args.hint if args.hint is not None else "learnt (%s)" % RZ._dev_state(dev).get("longest")),
+           "wave_priority": not args.no_priority,
            "shader_clock_mhz_under_load": round(sclk, 1),
            "fwd": analyse(h[:NB], "k_composite_fwd_tiles", None), "bwd": analyse(h[NB:], "k_composite_bwd_tiles", None)}
     print(json.dumps(out, indent=1))
