@@ -339,6 +339,7 @@ def main():
 
     def step():  # one view at a time on the current stream (calibration of the per-kernel table, and the single-view-in-flight number)
         L = lanes[0]
+        sess.wave_priority = True  # a view on its own (the views-in-flight groups switch it off for their launches)
         sess.forward(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
         sess.backward(L["gout"])
 
@@ -424,6 +425,7 @@ def main():
     if not args.headline_only:
         def step_s2():
             L = lanes[0]
+            sess.wave_priority = True
             sess.forward(L["m3"], L["col"], L["opa"], L["sca"], L["rot"], L["view"], L["proj"], rs.bg, rs.tanfovx, rs.tanfovy, 1.0)
             sess.backward(L["gout"], color_grad=False)
         el_s2_one = timed(step_s2, n_single, 5)

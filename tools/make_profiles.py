@@ -57,10 +57,13 @@ def main(d, tag):
             out["workload"] = {"W": int(m.group(1)), "H": int(m.group(2)), "P": int(m.group(3)), "R": int(m.group(4))}
     names = {"k_composite_bwd": "composite_bwd", "k_composite_fwd": "composite_fwd", "k_composite_bwd_tiles": "composite_bwd", "k_composite_fwd_tiles": "composite_fwd",
              "k_preprocess": "preprocess", "k_preprocess_bwd": "preprocess_bwd", "k_scatter": "scatter", "k_sort_wave": "sort"}
-    for k, v in agg.items():
+    for k0, v in agg.items():
+        k = k0.split("<")[0]  # template instances: the one-view command only runs <true> (all six gradients / state kept); <false> never overrides it
+        if k0.endswith("<false>") and names.get(k) in out:
+            continue
         if k in names and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             f, w = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
-            e = {"kernel": k, "hbm_bytes_per_launch": int((2 * f + w) * 1024), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1)}
+            e = {"kernel": k0, "hbm_bytes_per_launch": int((2 * f + w) * 1024), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1)}
             if "SQ_INSTS_VALU" in v:
                 e["valu_wave_instructions_per_launch"] = sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"])
             out[names[k]] = e
