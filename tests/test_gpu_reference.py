@@ -257,6 +257,17 @@ def test_view_interp_script_runs_unmodified(tmp_path):
     print(res)
 
 
+def test_real_data_script_runs_unmodified(tmp_path):
+    """test_real_data.py as __main__: the reference's third entry point -- one novel view per frame of a captured sequence, the novel camera at
+    --ratio between the two source cameras (lib/utils.get_novel_calib), the reference's pts2render on the HIP rasteriser, one JPEG per frame."""
+    res = _tool([os.path.join(ROOT, "tools", "run_reference.py"), "real", "--res", "256", "--samples", "3", "--ratio", "0.35", "--write-images", "--work", str(tmp_path / "w")])
+    assert res["frames"] == 3 and res["frames_per_s_end_to_end"] > 0
+    for im in res["images"]:
+        assert im["shape"] == [512, 512, 3] and im["nonblack_fraction"] > 0.02, im
+    assert sorted(os.listdir(tmp_path / "w" / "test_out")) == sorted(im["file"] for im in res["images"])
+    print(res)
+
+
 def test_train_stage2_script_runs_unmodified(tmp_path):
     """train_stage2.py as __main__ (one process; BASELINE config 4's iteration at a reduced size): real data set class + DataLoader workers, real
     networks under AMP, the reference's pts2render -> HIP rasteriser, L1 + SSIM, GradScaler backward through the HIP backward, AdamW."""

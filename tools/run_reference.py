@@ -2,6 +2,7 @@
 """Run the reference's OWN scripts, unmodified, on the MI355X drop-in and time them (BASELINE configs 3 and 4; harness, not product).
 
     python tools/run_reference.py interp [--samples 2] [--views 5] [--res 1024]      test_view_interp.py   (config 3)
+    python tools/run_reference.py real [--samples 2] [--ratio 0.5] [--res 1024]       test_real_data.py     (one novel view per frame)
     python tools/run_reference.py train  [--steps 12] [--batch 2] [--res 1024]       train_stage2.py       (config 4, one process)
 
 The reference is found by tools/refenv.reference_dir(): /root/reference in the build container, the bytecode build in the git-ignored
@@ -173,6 +174,55 @@ def interp(args):
     return out
 
 
+def real(args):
+    """test_real_data.py as `__main__`: the reference's third entry point (one novel view per captured frame, `get_novel_calib` at --ratio between the
+    two source cameras, `pts2render`, JPEG per frame) on the synthetic set in the loader's on-disk layout."""
+    import numpy as np
+    import torch
+
+    ref = refenv.reference_dir(args.reference)
+    if ref is None:
+        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+    refenv.activate(ref)
+    work = os.path.abspath(args.work)
+    data_root = _dataset(work, args.res, 0, args.samples, args.fill)
+    refenv.make_workdir(ref, work, {"dataset": {"src_res": args.res}})
+    os.chdir(work)
+    cfg = _cfg(work)
+    from lib.network import RtStereoHumanModel
+    torch.manual_seed(1314)
+    ckpt = os.path.join(work, "random_init_stage2.pth")
+    torch.save({"network": RtStereoHumanModel(cfg, with_gs_render=True).state_dict()}, ckpt)
+    import cv2
+    stamps, written = [], []
+    real_imwrite = cv2.imwrite
+
+    def imwrite(path, img):
+        torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+        written.append((path, tuple(img.shape), float((np.asarray(img).max(-1) > 8).mean())))
+        return real_imwrite(path, img) if args.write_images else True
+    cv2.imwrite = imwrite
+    argv = ["test_real_data", "--test_data_root", os.path.join(data_root, "val"), "--ckpt_path", ckpt, "--src_view", "0", "1", "--ratio", str(args.ratio)]
+    for rep in range(2):  # the second run is the measured one
+        del stamps[:], written[:]
+        old = sys.argv
+        sys.argv = argv
+        t0 = time.perf_counter()
+        try:
+            runpy.run_path(refenv.script(ref, "test_real_data"), run_name="__main__")
+        finally:
+            sys.argv = old
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    out = {"mode": "real", "reference": ref, "script": os.path.basename(refenv.script(ref, "test_real_data")), "res": args.res,
+           "render": "%dx%d" % (2 * args.res, 2 * args.res), "frames": len(written), "wall_s": round(wall, 3),
+           "frames_per_s_end_to_end": round(len(written) / wall, 3), "ratio": args.ratio,
+           "images": [{"file": os.path.basename(p_), "shape": list(sh), "nonblack_fraction": round(nb, 4)} for p_, sh, nb in written]}
+    print(json.dumps(out))
+    return out
+
+
 def train(args):
     """train_stage2.py as __main__, one process, the reference's real data set class on the synthetic set, real networks, random init."""
     import numpy as np
@@ -255,7 +305,7 @@ def ddp(args):
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
-    ap.add_argument("mode", choices=("interp", "train", "ddp"))
+    ap.add_argument("mode", choices=("interp", "real", "train", "ddp"))
     ap.add_argument("--reference", default=None)
     ap.add_argument("--work", default=os.environ.get("GPSGS_REF_WORK", "/tmp/gpsgs_ref_work"))
     ap.add_argument("--res", type=int, default=1024, help="source resolution (dataset.src_res); the render is 2x that (use_hr_img)")
@@ -267,8 +317,9 @@ def main():
     ap.add_argument("--train-samples", type=int, default=4)
     ap.add_argument("--eval-freq", type=int, default=0)
     ap.add_argument("--write-images", action="store_true")
+    ap.add_argument("--ratio", type=float, default=0.5, help="real: position of the novel camera between the two source cameras")
     args = ap.parse_args()
-    return {"interp": interp, "train": train, "ddp": ddp}[args.mode](args)
+    return {"interp": interp, "real": real, "train": train, "ddp": ddp}[args.mode](args)
 
 
 if __name__ == "__main__":
