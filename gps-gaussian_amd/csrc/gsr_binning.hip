@@ -221,113 +221,6 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     }
 }
 
-// The same scan for grids of up to 16,384 bins (a 1024^2 image: BASELINE config 2) in ONE workgroup: every thread owns 16 consecutive indices,
-// so there are no partials to publish, no flags to wait for and no second workgroup to be scheduled -- the fused 16-workgroup form spends most of
-// its ~12 us on exactly that (launch of 16 x 1024 threads, one release / acquire round trip through the L2s of eight XCDs, a serial walk over the
-// partials).  Outputs are bit-identical to k_scan_b's (same class order, patch order inside a class; tests/test_gpu_raster.py compares both forms).
-constexpr int SCAN1_K = 16;
-__global__ __launch_bounds__(SB) void k_scan_one(const uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_offset,
-                                                 uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ wg_order, int NB, int bx, int by, int64_t cap,
-                                                 GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
-                                                 uint32_t *__restrict__ host_hdr, uint32_t host_seq, int no_large_sort, uint32_t hint) {
-    static_assert(GSR_CPAD == 1, "k_scan_one reads the counters as contiguous words");
-    __shared__ uint32_t wsum[SB / 64];
-    __shared__ uint32_t smax[SB / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int base = tid * SCAN1_K;
-    uint32_t c[SCAN1_K], wbv[SCAN1_K];
-    uint32_t sum_c = 0, mx = 0, n_w0 = 0, n_w1 = 0;  // packed class counters as in k_scan_a/b: w0 = class 0 | class 1 << 16, w1 = class 2 | idle << 16
-    uint32_t clsbits = 0;                          // 2 bits per owned index: its class (0..3); indices without a bin are marked in `nobin`
-    uint32_t nobin = 0;
-#pragma unroll
-    for (int j = 0; j < SCAN1_K; j++) {
-        const int b = base + j;
-        c[j] = b < NB ? bin_count[b] : 0u;
-        sum_c += c[j];
-        mx = c[j] > mx ? c[j] : mx;
-        const int wb = tiled_bin((uint32_t)b, bx, by);
-        const uint32_t wc = wb >= 0 ? bin_count[wb] : 0u;
-        const int cls = work_class(wb, wc, hint);
-        wbv[j] = (uint32_t)wb;
-        if (cls < 0) nobin |= 1u << j;
-        else clsbits |= (uint32_t)cls << (2 * j);
-        n_w0 += class_w0(cls);
-        n_w1 += class_w1(cls);
-    }
-    // per-Gaussian slot prefix (training) first: it does not depend on the bins
-    uint32_t tot_slots = 0;
-    if (gpart) {
-        uint32_t carry = 0;
-        for (int g0 = 0; g0 < n_gblocks; g0 += SB) {
-            const int k = g0 + tid;
-            const uint32_t v = k < n_gblocks ? gpart[k] : 0u;
-            uint32_t tot;
-            const uint32_t ex = block_exscan(v, wsum, &tot);
-            if (k < n_gblocks) gpart[k] = carry + ex;
-            carry += tot;
-        }
-        tot_slots = carry;
-    }
-    uint32_t tot_sum32, tot_w0, tot_w1;
-    const uint32_t pre_sum = block_exscan(sum_c, wsum, &tot_sum32);  // < 2^32: at most 16,384 bins of at most P entries each is checked against cap below in 64 bits
-    const uint32_t pre_w0 = block_exscan(n_w0, wsum, &tot_w0);
-    const uint32_t pre_w1 = block_exscan(n_w1, wsum, &tot_w1);
-    // 64-bit total (a total beyond 2^32 must read as an overflow, not wrap below the capacity): per-wave sums of at most 64 x 16 counters
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t y = __shfl_xor(mx, d, 64);
-        mx = y > mx ? y : mx;
-    }
-    uint64_t s64 = sum_c;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s64 += __shfl_xor((unsigned long long)s64, d, 64);
-    __shared__ uint64_t ssum64[SB / 64];
-    __syncthreads();
-    if (lane == 0) { smax[wid] = mx; ssum64[wid] = s64; }
-    __syncthreads();
-    uint32_t tot_max = 0;
-    uint64_t tot_sum = 0;
-#pragma unroll
-    for (int w = 0; w < SB / 64; w++) { tot_max = smax[w] > tot_max ? smax[w] : tot_max; tot_sum += ssum64[w]; }
-    const uint32_t tot0 = tot_w0 & 0xffffu, tot1 = tot_w0 >> 16, tot2 = tot_w1 & 0xffffu;
-    const uint32_t tot_busy = tot0 + tot1 + tot2;
-    if (tid == 0) {
-        bin_offset[NB] = (uint32_t)tot_sum;
-        hdr->num_rendered = tot_sum;
-        const bool ovf_b = (int64_t)tot_sum > cap || (int64_t)tot_slots > cap || (no_large_sort && tot_max > 1024u) || hdr->row_overflow != 0u;
-        hdr->overflow = ovf_b ? 1u : 0u;
-        hdr->max_tile_count = tot_max;
-        hdr->num_busy_wgs = tot_busy;
-        hdr->num_slots = tot_slots;
-        if (host_hdr) {  // early notification, as in k_scan_b
-            const uint32_t ovf = ovf_b ? 1u : 0u;
-            volatile uint32_t *h = host_hdr;
-            h[0] = (uint32_t)tot_sum; h[1] = (uint32_t)(tot_sum >> 32); h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = hdr->num_points;
-            __threadfence_system();
-            __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    uint32_t off = pre_sum;
-    uint32_t r[4] = {pre_w0 & 0xffffu, tot0 + (pre_w0 >> 16), tot0 + tot1 + (pre_w1 & 0xffffu), tot_busy + (pre_w1 >> 16)};  // next position per class
-#pragma unroll
-    for (int j = 0; j < SCAN1_K; j++) {
-        const int b = base + j;
-        if (b < NB) {
-            bin_offset[b] = off;
-            bin_cursor[b] = off;
-        }
-        off += c[j];
-        if (!((nobin >> j) & 1u)) {
-            const uint32_t cls = (clsbits >> (2 * j)) & 3u;
-            // (a select chain instead of r[cls]: a dynamically indexed register array would go to scratch)
-            const uint32_t pos = cls == 0u ? r[0] : cls == 1u ? r[1] : cls == 2u ? r[2] : r[3];
-            r[0] += cls == 0u; r[1] += cls == 1u; r[2] += cls == 2u; r[3] += cls == 3u;
-            wg_order[pos] = wbv[j];
-        }
-    }
-}
-
-
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, const uint32_t *__restrict__ row_range, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
                                                             const uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
                                                             const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
@@ -573,12 +466,9 @@ void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *
                      uint32_t order_hint, hipStream_t s) {
     const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB: ragged patches at the grid edge)
     const int nblocks = ((NT > NB ? NT : NB) + SB - 1) / SB;
-    const char *form = getenv("GPSGS_SCAN");  // GPSGS_SCAN=multi keeps the multi-workgroup forms for every size (A/B and the equality test); read per call
-    if (!(form && form[0] == 'm') && nblocks <= SCAN1_K) {
-        hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SB), 0, s, bin_count, bin_offset, bin_cursor, wg_order, NB, bx, by, cap, hdr, gpart, n_gblocks, host_hdr,
-                           host_seq, no_large_sort ? 1 : 0, order_hint);
-        return;
-    }
+    // (Tried: ONE 1,024-thread workgroup owning 16 indices per thread for grids of up to 16,384 bins -- no partials, no flags.  Bit-identical
+    //  outputs, but 40.8 us against the fused form's 14.6: sixteen dependent rounds of patch-order index arithmetic and gathers on one CU cost far
+    //  more than the release / acquire round trip they avoid.  Removed; profiles/r03_issue_probes.md section 4.)
     if (nblocks <= GSR_SCAN_FUSE_MAX) {
         hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap,
                            hdr, gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0, order_hint);

@@ -436,32 +436,6 @@ def test_wave_priority_flag_changes_no_bit(monkeypatch):
             np.testing.assert_array_equal(out["1"][2][k], out["0"][2][k])
 
 
-@pytest.mark.parametrize("size", [(256, 256, 30000), (333, 277, 20000), (1024, 1024, 600000), (1024, 520, 150000)], ids=lambda c: "%dx%d_P%d" % c)
-def test_one_workgroup_scan_equals_the_multi_workgroup_scan(size, monkeypatch):
-    """Grids of up to 16,384 bins are scanned by ONE workgroup (k_scan_one: 16 indices per thread, no partials, no flags); GPSGS_SCAN=multi
-    keeps the fused multi-workgroup form.  Both must leave the same bin ranges, the same sorted lists, the same work order effects: image,
-    radii, per-pixel state and every gradient bit for bit."""
-    from gps_gaussian_amd import rasterizer as RZ
-    from gps_gaussian_amd import synthetic as S
-    W, H, P = size
-    g = S.make_scene(W, P) if W == H and W in (256, 1024) else S.make_uniform_cloud(P, W, H, seed=77, scale_med=0.01, z_range=(0.5, 5.0), behind_frac=0.05)
-    dpix = np.random.default_rng(5).standard_normal((3, g["H"], g["W"])).astype(np.float32)
-    res = {}
-    for form in ("one", "multi"):
-        monkeypatch.setenv("GPSGS_SCAN", form)
-        img, radii, grads, info = hip_render(g, dpix)
-        st = RZ.export_state(info["ws"], g["means3D"].shape[0], g["W"], g["H"], info["cap"])
-        res[form] = (img, radii, grads, {k: v.cpu().numpy() for k, v in st.items() if hasattr(v, "cpu")})
-    a, b = res["one"], res["multi"]
-    np.testing.assert_array_equal(a[0], b[0])
-    np.testing.assert_array_equal(a[1], b[1])
-    for k in a[2]:
-        np.testing.assert_array_equal(a[2][k], b[2][k])
-    assert set(a[3]) == set(b[3]) and {"ranges", "point_list", "n_contrib", "final_T"} <= set(a[3])
-    for k in a[3]:
-        np.testing.assert_array_equal(a[3][k], b[3][k])
-
-
 def test_stale_gradient_records_of_an_earlier_view_are_never_read():
     """The per-instance gradient records live in slots that belong to (Gaussian, cell of its bin rect) and are reused from view to
     view; a flag byte per slot -- cleared by k_scatter, set by the compositing backward -- says whether THIS backward wrote the
