@@ -34,6 +34,22 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.gpsgs_build_info()
 
 
+def test_python_constants_mirror_the_header():
+    """Every GSR_FLAG_* / GPSGS_E_* the ctypes shim uses has the value include/gpsgs.h gives it (a flag added on one side only would
+    silently select a different kernel path)."""
+    src = open(os.path.join(ROOT, "include", "gpsgs.h")).read()
+    flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(GSR_FLAG_[A-Z_]+)\s+(\d+)u\b", src)}
+    assert {"GSR_FLAG_DEBUG", "GSR_FLAG_TIMING", "GSR_FLAG_NO_LARGE_SORT", "GSR_FLAG_COMPOSITE_TILES", "GSR_FLAG_NO_COLOR_GRAD", "GSR_FLAG_WAVE_PRIORITY"} <= set(flags)
+    for name, value in flags.items():
+        assert getattr(_capi, name) == value, name
+    vals = sorted(flags.values())
+    assert all(v & (v - 1) == 0 for v in vals) and len(set(vals)) == len(vals)   # distinct single bits
+    assert not any(v & 0xf0 for v in vals)                                       # bits 4..7 carry the stage of GSR_FLAG_TIMING_STAGE
+    errs = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(GPSGS_E_[A-Z_]+)\s*=\s*(-?\d+)", src)}
+    assert errs and all(getattr(_capi, k) == v for k, v in errs.items() if hasattr(_capi, k))
+    assert _capi.GPSGS_E_INTERNAL == errs["GPSGS_E_INTERNAL"]
+
+
 def test_code_object_targets_gfx950():
     out = subprocess.run(["strings", "-a", _capi.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     assert "gfx950" in out
