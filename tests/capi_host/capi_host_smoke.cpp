@@ -157,6 +157,23 @@ int main() {
                 if (pass == 0 ? col[k] != hgc[k] : col[k] != 0.f) { printf("row-range dL_dcolors wrong at %d (pass %d)\n", k, pass); return 1; }
             }
         }
+        // GSR_FLAG_WAVE_PRIORITY is a scheduling hint: forward and backward with it must reproduce every bit
+        {
+            const unsigned PF = TF | GSR_FLAG_WAVE_PRIORITY;
+            rc = gsr_forward_ex(Pcap, W, H, wm, wc, wo, wsc, wr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color2, radii2, ws2, nb2, cap, PF, st, nullptr, 0u, &ext);
+            if (rc == GPSGS_OK)
+                rc = gsr_backward_ex(Pcap, W, H, wm, wc, wo, wsc, wr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, radii2, dgp, w3, w2, wgc, wgo, wgs, wgr, ws2, nb2, cap, PF, st, &ext);
+            if (rc != GPSGS_OK) { printf("wave-priority pass rc=%d\n", rc); return 1; }
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(img2.data(), color2, img2.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < img.size(); k++) if (img2[k] != img[k]) { printf("wave-priority image differs at %zu\n", k); return 1; }
+            std::vector<float> a(3 * P), b(3 * P), col(3 * P);
+            CK(hipMemcpy(a.data(), g3, 12 * P, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), w3 + 3 * P, 12 * P, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(col.data(), wgc + 3 * P, 12 * P, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 3 * P; k++)
+                if (a[k] != b[k] || col[k] != hgc[k]) { printf("wave-priority gradients differ at %d\n", k); return 1; }
+        }
         // a range longer than the capacity is reported like an overflow
         std::vector<uint32_t> big = {0u, (uint32_t)(3 * P)};
         uint32_t *dbig = dev(big);
