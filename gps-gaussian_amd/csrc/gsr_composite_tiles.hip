@@ -102,7 +102,7 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
                 st.C2 += c.w * w;
                 st.T = T_next;
                 if (KEEP) st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
-#ifdef GSR_ABL_VALU  // issue probes (tools/gpu_r03_n.sh; never defined in a product build): extra work per pair that changes no result
+#ifdef GSR_ABL_VALU  // issue probes (tools/gpu_runs/gpu_r03_n.sh; never defined in a product build): extra work per pair that changes no result
                 { float d0_, d1_; __asm__ volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %2, %2" : "=v"(d0_), "=v"(d1_) : "v"(c.y)); }
 #endif
 #ifdef GSR_ABL_SALU

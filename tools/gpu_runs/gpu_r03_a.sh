@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call A: the reference's own code on the HIP drop-in (tests + configs 3 / 4 at full size), the new bench.py launch tests
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 ls oracle/_ref/GPS-Gaussian | head -3

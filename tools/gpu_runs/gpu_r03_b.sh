@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call B: locate the config-3 memory fault, full GPU suite with the hardened / new tests, bench line
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 echo "=== repro 1: faulthandler only"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call D: the fix of the count / scatter threshold mismatch -- config 3 repro (both families, validated lists), full GPU suite, bench line
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 for fam in tiles valu; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call E: profiles (kernel stats, PMC, traffic) + the full pipeline at BASELINE sizes (configs 3 and 4)
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 bash tools/prof_r03.sh r03 > gpurun_out/r03/prof.log 2>&1; tail -5 gpurun_out/r03/prof.log | cut -c1-600

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call F: full GPU suite (parity report of the round) + bench line with the stage-2 gradient set
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_report.jsonl

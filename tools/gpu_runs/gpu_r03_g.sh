@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call G: smoke, full GPU suite, final bench line, sampler drop-in host cost
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call I: final verification -- full GPU suite (-x, as the driver runs it), bench line, config 4 with the exchange step issued through RCCL
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_report.jsonl

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call J: sessions with explicit streams -- session tests + bench line
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_raster.py tests/test_gpu_bench_contract.py -x -q -m gpu -k "session or bench or contract or ranks or rccl or gpus" 2>&1 | tail -3

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call K2: large-list sort on up to 1,024 workgroups -- sort-path tests, config 3 timed, rocprofv3 kernel stats of config 3
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 ROOT=$PWD
 mkdir -p gpurun_out/prof_r03_config3 gpurun_out/r03
 export TMPDIR=/tmp

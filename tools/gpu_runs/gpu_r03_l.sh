@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call L: final state -- full GPU suite as the driver runs it, the round's profiles regenerated from HEAD, bench line
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_report.jsonl

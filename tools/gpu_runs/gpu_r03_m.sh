@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call M: A/B of compositing-kernel variants on ONE box (clocks differ between boxes): per-kernel hipEvent times of the step for
 # each prebuilt library under gps-gaussian_amd/lib/variants/, then the raster parity tests + a short bench on the candidate (last variant named)
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 VARIANTS=${VARIANTS:-"base e1 e5 base e1 e5"}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call N: sensitivity probes of the compositing kernels (extra VALU / SALU / transcendental work per pair, results unchanged) and the
 # parity failure of call M looked at per variant
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 L=gps-gaussian_amd/lib

@@ -1,21 +1,22 @@
 #!/bin/bash
-# round 3, GPU call O: how the compositing kernels scale with the waves resident per SIMD (GPSGS_DEBUG_LDS_PAD), wave priority by remaining work
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+# round 3, GPU call P: compositing kernels with more waves resident per SIMD (B operands of the exponent MFMAs from a device table, the backward's
+# dL/dpixel rows in LDS): variants, a dense scene (config 5), parity
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 L=gps-gaussian_amd/lib
-OUT=gpurun_out/r03/call_o.log
+OUT=gpurun_out/r03/call_p.log
 : > $OUT
 show() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['stages_us']; print('fwd %.2f bwd %.2f step %.1f views/s %.0f' % (s['composite_fwd'], s['composite_bwd'], d['sum_us'], d['views_per_s']))"; }
-cp $L/variants/g0.so $L/libgpsgs_hip.so
-for pad in 0 8000 11500 18000 38000 6000 3000; do
-  echo "== g0 pad $pad" | tee -a $OUT; GPSGS_DEBUG_LDS_PAD=$pad timeout 300 python tools/stage_times.py --families tiles --steps 60 2>&1 | tail -1 | show | tee -a $OUT
-done
 for v in $VARIANTS; do
   cp $L/variants/$v.so $L/libgpsgs_hip.so
   echo "== $v" | tee -a $OUT; timeout 300 python tools/stage_times.py --families tiles --steps 100 2>&1 | tail -1 | show | tee -a $OUT
+done
+for v in $DENSE; do
+  cp $L/variants/$v.so $L/libgpsgs_hip.so
+  echo "== $v config 5 (2048^2, 2.4 M)" | tee -a $OUT; timeout 300 python tools/stage_times.py --families tiles --res 2048 --gaussians 2400000 --steps 20 2>&1 | tail -1 | show | tee -a $OUT
 done
 for v in $PARITY; do
   cp $L/variants/$v.so $L/libgpsgs_hip.so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call Q: wave priority -- forward by remaining work (default now), backward second-generation workgroups first; bench lines
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 L=gps-gaussian_amd/lib

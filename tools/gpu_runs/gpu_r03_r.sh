@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call R: GSR_FLAG_WAVE_PRIORITY end to end (kernel times with the flag on / off, the bitwise test, raster parity), and the forward's
 # colour sum by parts against the plain form with several views in flight (bench `value`)
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 L=gps-gaussian_amd/lib

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call S: the backward without the wave-uniform skip of entries no pixel blends (a branch per entry on a VALU -> SALU round trip)
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 L=gps-gaussian_amd/lib

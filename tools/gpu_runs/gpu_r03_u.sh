@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call U: one-workgroup scan against the fused multi-workgroup form (stage times), full GPU suite (incl. the scan equality test and
 # test_real_data.py as __main__), bench line
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 OUT=gpurun_out/r03/call_u.log
