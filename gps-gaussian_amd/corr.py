@@ -6,6 +6,7 @@ Interface bound by the reference at /root/reference/core/corr.py:22,28:
 Both return 1-tuples.  fp32 and fp16 volumes (stage 2 runs the update block under AMP).  No CPU fallback.
 """
 import ctypes as C
+import sys
 
 import torch
 
@@ -49,8 +50,12 @@ def _call(fn, what, dev, *args):
 
 def forward(volume, coords, radius):
     global _lib
-    lib = _lib or _capi.lib()
-    _lib = lib
+    lib = _lib
+    if lib is None:
+        lib = _lib = _capi.lib()
+        acc = sys.modules.get("gps_gaussian_amd.accelerate")  # first sampler call of the process: the opt-in hook's safety net (accelerate.py)
+        if acc is not None and acc._armed:
+            acc.late_apply()
     N, H1, W1, W2, c = _args(volume, coords)
     v = volume if volume.is_contiguous() else volume.contiguous()
     out = torch.empty((N, 2 * radius + 1, H1, W1), dtype=v.dtype, device=v.device)

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "gsr_common.h"
 
 namespace {
@@ -207,14 +209,26 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     if (trace_on() || (flags & GSR_FLAG_DEBUG)) {  // self-check between the sort and the compositing (synchronises; never in normal operation)
+        // everything on the caller's stream `s` and checked: PyTorch's side streams do not synchronise with the NULL stream, so a NULL-stream memset of
+        // the counters could land AFTER k_validate_lists' atomics and hide a real inconsistency.  The five counters live in a small
+        // device buffer allocated once per process (a debug forward is never captured, but it no longer allocates per call either).
         GsrHeader h;
-        unsigned long long *d_out = nullptr, h_out[5] = {0, 0, 0, 0, 0};
-        if (hipMemcpy(&h, hdr, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || hipMalloc(&d_out, sizeof(h_out)) != hipSuccess) return GPSGS_E_LAUNCH;
-        (void)hipMemset(d_out, 0, sizeof(h_out));
+        unsigned long long h_out[5] = {0, 0, 0, 0, 0};
+        static unsigned long long *d_out_by_dev[64] = {nullptr};
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return GPSGS_E_LAUNCH;
+        unsigned long long *d_out;
+        {
+            static std::mutex mu;
+            std::lock_guard<std::mutex> g(mu);
+            if (!d_out_by_dev[devid] && hipMalloc(&d_out_by_dev[devid], sizeof(h_out)) != hipSuccess) return GPSGS_E_LAUNCH;
+            d_out = d_out_by_dev[devid];
+        }
+        if (hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemsetAsync(d_out, 0, sizeof(h_out), s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            return GPSGS_E_LAUNCH;
         if (!h.overflow) hipLaunchKernelGGL(k_validate_lists, dim3((L.NB + 255) / 256), dim3(256), 0, s, P, L.NB, bin_offset, bin_cursor, point_list, splats, d_out);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost);
-        (void)hipFree(d_out);
+        if (hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return GPSGS_E_LAUNCH;
         const bool bad = h_out[0] || h_out[1] || h_out[4];
         if (trace_on() || bad) {
             fprintf(stderr, "[gpsgs] header: R=%llu overflow=%u longest=%u busy=%u slots=%u points=%u | lists: ids out of range %llu, out of order %llu, non-finite records %llu, "

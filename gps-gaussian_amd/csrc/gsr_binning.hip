@@ -441,7 +441,163 @@ __global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ b
     else sort_wave_regs<16>(seg, n, out, lane);
 }
 
-// lists longer than 1024 keys: a persistent grid of 1024-thread workgroups (128 KiB LDS each: one resident per CU) strides over the bins
+// ---- lists of 1,025 .. 8,192 keys: 1 / 2 / 4 waves per list, 32 keys per lane in registers -------------------------------------------
+// What freshly initialised networks produce (BASELINE configs 3 / 4 with random weights: scales at their 0.01 m clamp, ~20,000 bins with
+// lists of 1,000-3,000 entries per 2048^2 view).  Rounds 1-3 sorted such a list with ONE 1,024-thread workgroup in 128 KiB of LDS, one key
+// per thread and a workgroup barrier after each of the 66-78 network stages: barrier-latency bound, one list per CU at a time, 1.9 ms per
+// view = 2.4 % of the HBM roof (profiles/r03_config3_kernel_stats.md).  Here the network of k_sort_wave is kept -- element e = t * 32 + r
+// (t = thread of the workgroup, r = register), partners e ^ mask -- so of the 66 stages of a 2,048-key sort 45 are register-to-register
+// and 21 are lane exchanges (DPP / LDS crossbar), with no barrier and no LDS memory traffic at all for one wave; with 2 / 4 waves the 2 / 4
+// stages whose mask reaches across waves go through a transposed LDS tile (conflict-free) behind two barriers.  The network is walked by
+// RUNTIME loops over (level, stage) that dispatch into ~20 straight-line stage bodies (one per register / lane mask): ~35 KiB of code instead
+// of ~120 KiB for the fully unrolled form, which would stream through the instruction cache once per list.
+// Keys arrive unsorted, so they are loaded coalesced (register r = keys r * T + t) and only the sorted ids are written in element order.
+constexpr int SM_KPL = 32, SM_LOGK = 5;
+
+template <uint32_t LM>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v) {
+    return ((uint64_t)lane_xor<LM>((uint32_t)(v >> 32)) << 32) | lane_xor<LM>((uint32_t)v);
+}
+
+// both elements in this lane's registers: r <-> r ^ RM (ascending: the lower register index keeps the minimum)
+template <int RM>
+__device__ __forceinline__ void sm_inreg(uint64_t (&key)[SM_KPL]) {
+#pragma unroll
+    for (int r = 0; r < SM_KPL; r++) {
+        const int r2 = r ^ RM;
+        if (r2 > r) {
+            const uint64_t a = key[r], b = key[r2];
+            const bool sw = a > b;
+            key[r] = sw ? b : a;
+            key[r2] = sw ? a : b;
+        }
+    }
+}
+// partner in lane ^ LM, register r ^ RM (RM = 0: half-cleaner, RM = 31: flip).  Pairs of registers are handled together so that only two
+// exchanged keys are live at a time (the k_sort_wave form materialises all KPL of them first: 64 more VGPRs at 32 keys per lane).
+template <uint32_t LM, int RM>
+__device__ __forceinline__ void sm_cross(uint64_t (&key)[SM_KPL], bool lower) {
+#pragma unroll
+    for (int r = 0; r < SM_KPL; r++) {
+        const int r2 = r ^ RM;
+        if (r2 < r) continue;
+        const uint64_t mine = key[r], mine2 = key[r2];
+        const uint64_t got = lane_xor64<LM>(mine2);           // the partner lane's register r2 pairs with my register r
+        key[r] = ((got < mine) != !lower) ? got : mine;       // keys are unique: one compare, flipped for the upper lane (see sort_stage)
+        if (r2 != r) {
+            const uint64_t got2 = lane_xor64<LM>(mine);
+            key[r2] = ((got2 < mine2) != !lower) ? got2 : mine2;
+        }
+    }
+}
+__device__ __forceinline__ void sm_inreg_switch(uint32_t rm, uint64_t (&key)[SM_KPL]) {
+    switch (rm) {
+        case 1: sm_inreg<1>(key); break;
+        case 2: sm_inreg<2>(key); break;
+        case 3: sm_inreg<3>(key); break;
+        case 4: sm_inreg<4>(key); break;
+        case 7: sm_inreg<7>(key); break;
+        case 8: sm_inreg<8>(key); break;
+        case 15: sm_inreg<15>(key); break;
+        case 16: sm_inreg<16>(key); break;
+        default: sm_inreg<31>(key); break;
+    }
+}
+__device__ __forceinline__ void sm_clean_switch(int jl /* lane bit */, uint64_t (&key)[SM_KPL], int lane) {
+    const bool lower = ((lane >> jl) & 1) == 0;
+    switch (jl) {
+        case 0: sm_cross<1u, 0>(key, lower); break;
+        case 1: sm_cross<2u, 0>(key, lower); break;
+        case 2: sm_cross<4u, 0>(key, lower); break;
+        case 3: sm_cross<8u, 0>(key, lower); break;
+        case 4: sm_cross<16u, 0>(key, lower); break;
+        default: sm_cross<32u, 0>(key, lower); break;
+    }
+}
+__device__ __forceinline__ void sm_flip_switch(int kl /* lane bits the flip mirrors: 1..6 */, uint64_t (&key)[SM_KPL], int lane) {
+    const bool lower = ((lane >> (kl - 1)) & 1) == 0;
+    switch (kl) {
+        case 1: sm_cross<1u, 31>(key, lower); break;
+        case 2: sm_cross<3u, 31>(key, lower); break;
+        case 3: sm_cross<7u, 31>(key, lower); break;
+        case 4: sm_cross<15u, 31>(key, lower); break;
+        case 5: sm_cross<31u, 31>(key, lower); break;
+        default: sm_cross<63u, 31>(key, lower); break;
+    }
+}
+// a stage whose mask reaches across the waves of the workgroup: through LDS, register-major (xch[r * T + t]: lanes of a wave are adjacent words,
+// and t ^ tmask permutes whole 64-groups or lanes inside one -- no bank conflicts either way)
+template <int NW>
+__device__ __forceinline__ void sm_lds_stage(uint64_t (&key)[SM_KPL], uint64_t *xch, int t, uint32_t mask, uint32_t top) {
+    constexpr int T = NW * 64;
+    const uint32_t rm = mask & (SM_KPL - 1), tm = mask >> SM_LOGK;
+    const bool lower = (((uint32_t)t << SM_LOGK) & top) == 0;
+    __syncthreads();  // the previous exchange's reads are done
+#pragma unroll
+    for (int r = 0; r < SM_KPL; r++) xch[r * T + t] = key[r];
+    __syncthreads();
+    const uint32_t tp = (uint32_t)t ^ tm;
+    if (rm == 0) {
+#pragma unroll
+        for (int r = 0; r < SM_KPL; r++) {
+            const uint64_t got = xch[r * T + tp], mine = key[r];
+            key[r] = ((got < mine) != !lower) ? got : mine;
+        }
+    } else {  // flip: rm == 31
+#pragma unroll
+        for (int r = 0; r < SM_KPL; r++) {
+            const uint64_t got = xch[(r ^ (SM_KPL - 1)) * T + tp], mine = key[r];
+            key[r] = ((got < mine) != !lower) ? got : mine;
+        }
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void sort_multi(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, uint64_t *xch, int t) {
+    constexpr int T = NW * 64;
+    constexpr int LOGN = SM_LOGK + 6 + (NW == 1 ? 0 : NW == 2 ? 1 : 2);
+    const int lane = t & 63;
+    uint64_t key[SM_KPL];
+#pragma unroll
+    for (int r = 0; r < SM_KPL; r++) {
+        const uint32_t e = (uint32_t)(r * T + t);  // any assignment of the unsorted keys to elements will do: coalesced
+        key[r] = e < n ? seg[e] : ~0ull;
+    }
+    for (int kb = 1; kb <= LOGN; kb++) {  // merge sorted runs of 2^(kb-1) into runs of 2^kb: one flip, then half-cleaners of stride 2^j
+        if (kb <= SM_LOGK) sm_inreg_switch((1u << kb) - 1u, key);
+        else if (kb <= SM_LOGK + 6) sm_flip_switch(kb - SM_LOGK, key, lane);
+        else if (NW > 1) sm_lds_stage<NW>(key, xch, t, (1u << kb) - 1u, 1u << (kb - 1));
+        for (int j = kb - 2; j >= 0; j--) {
+            if (j < SM_LOGK) sm_inreg_switch(1u << j, key);
+            else if (j < SM_LOGK + 6) sm_clean_switch(j - SM_LOGK, key, lane);
+            else if (NW > 1) sm_lds_stage<NW>(key, xch, t, 1u << j, 1u << j);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < SM_KPL; r++) {
+        const uint32_t e = (uint32_t)t * SM_KPL + r;
+        if (e < n) out[e] = (uint32_t)key[r];
+    }
+}
+
+// A persistent grid strides over the BUSY bins in work order (wg_order: the longest lists first, so the stride deals them out evenly) and
+// sorts those whose length falls into this launch's class: (1024 << (NW/2)) < n <= 2048 * NW ... i.e. NW = 1: 1,025-2,048, 2: -4,096, 4: -8,192.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3))) void k_sort_multi(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                        const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                                                        const GsrHeader *__restrict__ hdr) {
+    __shared__ uint64_t xch[NW > 1 ? NW * 64 * SM_KPL : 1];
+    constexpr uint32_t HI = 2048u * NW, LO = NW == 1 ? 1024u : HI / 2u;
+    if (hdr->overflow || hdr->max_tile_count <= LO) return;
+    const uint32_t busy = hdr->num_busy_wgs;
+    for (uint32_t pos = blockIdx.x; pos < busy; pos += gridDim.x) {
+        const uint32_t bin = wg_order[pos];
+        const uint32_t off = bin_offset[bin], n = bin_offset[bin + 1] - off;  // workgroup-uniform
+        if (n > LO && n <= HI) sort_multi<NW>(keys + off, n, point_list + off, xch, threadIdx.x);
+    }
+}
+
+// lists longer than 8,192 keys: a persistent grid of 1024-thread workgroups (128 KiB LDS each: one resident per CU) strides over the bins
 // and picks them up (launching one big workgroup per bin just to exit cost ~18 us at 16,384 bins).  Rare in the synthetic configs (the
 // launch is left out until a long list has been seen on the device), the NORM with freshly initialised networks: BASELINE config 3 with random
 // weights has ~20,000 bins of 1,000-3,000 entries per view, and the 64-workgroup grid of rounds 1-2 took 6.0 ms of a 7.6 ms render there
@@ -449,10 +605,10 @@ __global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ b
 __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__restrict__ bin_offset, uint64_t *__restrict__ keys,
                                                      uint32_t *__restrict__ point_list, const GsrHeader *__restrict__ hdr) {
     __shared__ uint64_t sk[16384];
-    if (hdr->overflow || hdr->max_tile_count <= 1024u) return;
+    if (hdr->overflow || hdr->max_tile_count <= 8192u) return;
     for (int b = blockIdx.x; b < NB; b += gridDim.x) {
         const uint32_t off = bin_offset[b], n = bin_offset[b + 1] - off;  // wave-uniform
-        if (n > 1024u) {
+        if (n > 8192u) {
             sort_one_bin<1024, 16384, true>(sk, off, n, keys, point_list, threadIdx.x);
             __syncthreads();
         }
@@ -491,5 +647,10 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
     if (NB <= 0) return;
     hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     if (no_large_sort) return;  // the scan has turned any list longer than 1024 into an overflow (nothing downstream runs)
+    // 1,025 .. 8,192 keys: 1 / 2 / 4 waves per list, keys in registers (each launch returns at once when the view's longest list is below its class)
+    const int busy_max = NB;
+    hipLaunchKernelGGL(k_sort_multi<4>, dim3(busy_max < 1024 ? busy_max : 1024), dim3(256), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_multi<2>, dim3(busy_max < 2048 ? busy_max : 2048), dim3(128), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_multi<1>, dim3(busy_max < 4096 ? busy_max : 4096), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 1024 ? NB : 1024), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

@@ -10,6 +10,7 @@
 // v_exp_f32: the 8 VALU instructions per (pixel, splat) pair that computed dx, dy and the quadratic form are gone (forward 23 -> 15
 // per pair), for ~1.7 instructions per (bin, splat) of operand preparation and 4 cycles per (bin, splat) on the matrix pipe.
 // The backward's pair body needs no dx, dy either: its sums over the pixels are formed in a second phase with lane = (splat, pixel row).
+#include <atomic>
 #include <type_traits>
 
 #include "gsr_pow_tiles.h"
@@ -542,17 +543,24 @@ void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat
                                     GsrGradAcc *inst_grad, const GsrHeader *hdr, bool color_grad, bool wave_prio, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
-    // workgroups the chip holds at once (the first generation), per kernel instantiation: occupancy x compute units, asked once
-    static uint32_t resident[2] = {0u, 0u};
-    uint32_t &res = resident[color_grad ? 1 : 0];
-    if (wave_prio && res == 0u) {
+    // workgroups the chip holds at once (the first generation): occupancy x compute units, asked once per (device, kernel instantiation) and kept in
+    // relaxed atomics (a process may drive several GPUs from several host threads; a lost race only asks the runtime twice).  The LDS pad is a
+    // process-wide development knob (gsr_debug_lds_pad), so it is not part of the key.
+    static std::atomic<uint32_t> resident[64][2];
+    uint32_t res = 0u;
+    if (wave_prio) {
         int per_cu = 0, dev = 0, cus = 0;
-        const void *fn = color_grad ? reinterpret_cast<const void *>(k_composite_bwd_tiles<true>) : reinterpret_cast<const void *>(k_composite_bwd_tiles<false>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, gsr_debug_lds_pad()) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
-            res = (uint32_t)per_cu * (uint32_t)cus;
-        else
-            res = 0xffffffffu;  // unknown: no workgroup counts as a late starter
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+            res = 0xffffffffu;
+        } else if ((res = resident[dev][color_grad ? 1 : 0].load(std::memory_order_relaxed)) == 0u) {
+            const void *fn = color_grad ? reinterpret_cast<const void *>(k_composite_bwd_tiles<true>) : reinterpret_cast<const void *>(k_composite_bwd_tiles<false>);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, gsr_debug_lds_pad()) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+                res = (uint32_t)per_cu * (uint32_t)cus;
+            else
+                res = 0xffffffffu;  // unknown: no workgroup counts as a late starter
+            resident[dev][color_grad ? 1 : 0].store(res, std::memory_order_relaxed);
+        }
     }
     const uint32_t prio_from_wg = wave_prio ? res : 0u;
     if (color_grad)

@@ -20,4 +20,9 @@ def package():
 
 def submodule(name):
     package()
-    return importlib.import_module("gps_gaussian_amd." + name)
+    mod = importlib.import_module("gps_gaussian_amd." + name)
+    if os.environ.get("GPSGS_ACCELERATE"):
+        # opt-in (default off): rebind the reference's pts2render / l1_loss / ssim / CorrBlockFast1D / upsample_flow / flow2depth / depth2pc to
+        # the fused kernels as the reference's modules load -- accelerate.py; no reference file is touched
+        importlib.import_module("gps_gaussian_amd.accelerate").install()
+    return mod

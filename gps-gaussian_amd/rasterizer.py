@@ -24,6 +24,7 @@ Host-side design notes (MI355X-first, not a translation of upstream's C++ glue):
 """
 import ctypes as C
 import os
+import sys
 import threading
 import time
 from typing import NamedTuple
@@ -238,15 +239,18 @@ class defer_capacity_checks:
 
     def __exit__(self, et, ev, tb):
         todo, _tls.deferred = _tls.deferred, self.prev
-        if et is None:
-            for finish in todo:
+        # EVERY finish() runs, whatever the others do: each one waits for its header (capacity is learnt, the pinned slot returns to the ring,
+        # an overflowed forward is repaired).  Stopping at the first failure would leak the remaining slots for good.  The first
+        # error is re-raised afterwards -- unless an exception is already on its way out of the block, which then wins.
+        first = None
+        for finish in todo:
+            try:
                 finish()
-        else:  # an exception is on its way out: still wait for every header (capacity is learnt, pinned slots return to the ring)
-            for finish in todo:
-                try:
-                    finish()
-                except Exception:  # noqa: BLE001
-                    pass
+            except Exception as e:  # noqa: BLE001
+                if first is None:
+                    first = e
+        if et is None and first is not None:
+            raise first
         return False
 
 
@@ -585,6 +589,9 @@ class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
+        acc = sys.modules.get("gps_gaussian_amd.accelerate")  # present only when GPSGS_ACCELERATE is set (opt-in, accelerate.py)
+        if acc is not None and acc._armed:
+            acc.late_apply()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
                 grad_arena=None):

@@ -36,6 +36,7 @@ class RasterSession:
         self.ws, self.cap, self.nbytes = None, 0, 0
         self.allocations = 0  # workspace (re)allocations so far: 1 in steady state
         self._in, self._pending, self._cur = None, None, None
+        self._ws_streams = []  # streams that have launched on the current workspace (see _ensure_ws)
         if self.training:
             # one buffer, six contiguous gradient arrays carved out of it
             P_ = max(self.P, 1)
@@ -47,12 +48,24 @@ class RasterSession:
                 o += P_ * c
         self._ws_bytes = self.lib.gsr_workspace_bytes if self.training else self.lib.gsr_workspace_bytes_forward_only
 
-    def _ensure_ws(self, cap):
+    def _ensure_ws(self, cap, stream):
+        """The workspace for `cap` instances, allocated on `stream` -- the stream its kernels are launched on.  (allocated under PyTorch's
+        ambient current stream, the block belonged to THAT stream's pool while its kernels ran on `stream`; on replacement it went straight back to the
+        pool and a later ambient-stream allocation could reuse it under the in-flight forward / backward.)  A replaced workspace is handed back with
+        record_stream() for every stream the session ever launched on it, so the allocator waits for those kernels before reusing the block."""
         if self.ws is None or cap != self.cap:
+            old = self.ws
+            if old is not None:
+                for st in self._ws_streams:
+                    old.record_stream(st)
             self.nbytes = self._ws_bytes(self.P, self.W, self.H, cap)
-            self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=self.dev)
+            with torch.cuda.stream(stream):
+                self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=self.dev)
+            self._ws_streams = [stream]
             self.cap = cap
             self.allocations += 1
+        elif not any(st is stream or st == stream for st in self._ws_streams):
+            self._ws_streams.append(stream)
 
     @staticmethod
     def _chk(t, n, name):
@@ -71,7 +84,9 @@ class RasterSession:
         notification (and repairs an overflow).  Several sessions on several streams can so be started back to back -- independent views
         rendered concurrently -- before the host waits for any of them.  stream: the torch.cuda.Stream to enqueue on (the session only
         hands its raw handle to the C-ABI and owns all its buffers, so PyTorch's current stream need not be switched: ~8 us of host time per
-        `with torch.cuda.stream(...)` saved, three times per view); default: the current stream."""
+        `with torch.cuda.stream(...)` saved, three times per view); default: the current stream.  The INPUTS (and, for backward(), dL_dpix)
+        must already be ordered against that stream by the caller -- the session never inserts a wait; its own workspace is allocated on, and
+        tied to, the streams it launches on."""
         P, W, H, lib = self.P, self.W, self.H, self.lib
         ptrs = (self._chk(means3D, 3 * P, "means3D"), self._chk(colors, 3 * P, "colors"), self._chk(opacities, P, "opacities"),
                 self._chk(scales, 3 * P, "scales"), self._chk(rotations, 4 * P, "rotations"))
@@ -89,7 +104,7 @@ class RasterSession:
         st = RZ._dev_state(self.dev)
         stream = self._cur.cuda_stream
         flags = RZ._extra_flags | family
-        self._ensure_ws(cap)
+        self._ensure_ws(cap, self._cur)
         if P == 0:
             _capi.check(lib.gsr_forward(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
                                         self.nbytes, cap, flags, stream), "gsr_forward")
@@ -127,8 +142,7 @@ class RasterSession:
                 break
             if self.cap >= 0x7fffffff:
                 raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace layout can address" % R)
-            with torch.cuda.stream(self._cur):  # (the repair allocates a larger workspace: on the view's own stream)
-                self._enqueue(RZ._capacity_for(st, self.P))  # the in-flight kernels of the failed attempt exit at once on the overflow flag
+            self._enqueue(RZ._capacity_for(st, self.P))  # a larger workspace (allocated on the view's own stream); the in-flight kernels of the failed attempt exit at once on the overflow flag
         return self.color, self.radii
 
     def backward(self, dL_dpix, color_grad=True, stream=None):
@@ -141,11 +155,14 @@ class RasterSession:
         ptrs, fl, cam, family, _keep = self._in
         g = self._chk(dL_dpix, 3 * self.W * self.H, "dL_dpix")
         G = self.grads
+        bstream = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        if not any(st is bstream or st == bstream for st in self._ws_streams):
+            self._ws_streams.append(bstream)  # (the caller orders this stream against the forward's; the workspace must outlive both)
         if self.P > 0:
             rc = self.lib.gsr_backward(self.P, self.W, self.H, *ptrs, *fl, *cam, self.radii.data_ptr(), g, G["means3D"].data_ptr(),
                                        G["means2D"].data_ptr(), G["colors"].data_ptr(), G["opacities"].data_ptr(), G["scales"].data_ptr(),
                                        G["rotations"].data_ptr(), self.ws.data_ptr(), self.nbytes, self.cap,
                                        RZ._extra_flags | family | (0 if color_grad else _capi.GSR_FLAG_NO_COLOR_GRAD),
-                                       (stream if stream is not None else torch.cuda.current_stream(self.dev)).cuda_stream)
+                                       bstream.cuda_stream)
             _capi.check(rc, "gsr_backward")
         return G

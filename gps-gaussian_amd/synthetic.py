@@ -124,8 +124,14 @@ def depth2pc_np(inv_depth, extr, intr):
     return out.T.astype(np.float32)
 
 
-def make_stereo_sample(res=1024, n_gauss=600_000, seed=SEED, render_res=None, ratio=0.5, angle0=0.0):
+def make_stereo_sample(res=1024, n_gauss=600_000, seed=SEED, render_res=None, ratio=0.5, angle0=0.0, attributes="trained"):
     """One synthetic stereo pair in the reference's per-view map layout plus the novel camera.
+
+    attributes = "trained": the SURVEY section 8(d) distribution (scales ~ exp(N(ln 0.002, 0.35^2)) capped at 0.01 m, opacity sigmoid(N(2, 1.5^2))).
+    attributes = "untrained": what the regression heads emit with freshly initialised weights, i.e. what BASELINE configs 3 / 4 really render
+    offline and what stage-2 training STARTS from: every scale at (or just under) the 0.01 m clamp of lib/gs_parm_network.py:76, opacities
+    around sigmoid(0) = 0.5 -- splats of ~25 px radius at 2048^2, ~55 bins per Gaussian, per-bin lists of 1,000-3,000 entries
+    (profiles/r03_full_pipeline.md measured ~30 M (Gaussian, bin) instances per view with the real networks).
 
     Returns dict with 'lmain'/'rmain' -> {img[3,res,res] in [-1,1], xyz[res*res,3], pts_valid[res*res] bool,
     rot_maps[4,res,res], scale_maps[3,res,res], opacity_maps[1,res,res], intr, extr} and 'novel_view' -> novel_camera().
@@ -155,8 +161,14 @@ def make_stereo_sample(res=1024, n_gauss=600_000, seed=SEED, render_res=None, ra
         n_px = res * res
         q = rng.standard_normal((4, n_px)).astype(np.float32)
         q /= np.linalg.norm(q, axis=0, keepdims=True)
-        scale = np.minimum(0.01, np.exp(rng.normal(math.log(0.002), 0.35, (3, n_px)))).astype(np.float32)
-        opac = (1.0 / (1.0 + np.exp(-rng.normal(2.0, 1.5, (1, n_px))))).astype(np.float32)
+        if attributes == "untrained":
+            scale = np.minimum(0.01, rng.uniform(0.0085, 0.0115, (3, n_px))).astype(np.float32)
+            opac = (1.0 / (1.0 + np.exp(-rng.normal(0.0, 0.25, (1, n_px))))).astype(np.float32)
+        elif attributes == "trained":
+            scale = np.minimum(0.01, np.exp(rng.normal(math.log(0.002), 0.35, (3, n_px)))).astype(np.float32)
+            opac = (1.0 / (1.0 + np.exp(-rng.normal(2.0, 1.5, (1, n_px))))).astype(np.float32)
+        else:
+            raise ValueError("attributes must be 'trained' or 'untrained'")
         img = rng.uniform(-1.0, 1.0, (3, n_px)).astype(np.float32)
         out[name] = dict(
             img=img.reshape(3, res, res), xyz=depth2pc_np(inv, extr, intr), pts_valid=valid, depth=inv,
@@ -191,9 +203,9 @@ def compact_sample(sample):
     return {k: np.ascontiguousarray(np.concatenate(v, 0), dtype=np.float32) for k, v in parts.items()}
 
 
-def make_scene(res=1024, n_gauss=600_000, seed=SEED, render_res=None, ratio=0.5):
+def make_scene(res=1024, n_gauss=600_000, seed=SEED, render_res=None, ratio=0.5, attributes="trained"):
     """Compacted Gaussian cloud + camera for one novel view: the rasteriser's direct inputs."""
-    s = make_stereo_sample(res, n_gauss, seed, render_res, ratio)
+    s = make_stereo_sample(res, n_gauss, seed, render_res, ratio, attributes=attributes)
     g = compact_sample(s)
     cam = s["novel_view"]
     g.update(

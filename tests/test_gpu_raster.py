@@ -213,9 +213,16 @@ def test_config2_full_size_vs_oracle_and_properties():
     np.testing.assert_array_equal(img5, img)
 
 
-@pytest.mark.parametrize("n,expect_path", [(5000, "lds_small"), (24000, "lds_large"), (110000, "global")])
+_SORT_CLASSES = {"regs_1_wave_16_keys": (1, 1024), "regs_1_wave_32_keys": (1025, 2048), "regs_2_waves": (2049, 4096), "regs_4_waves": (4097, 8192),
+                 "lds_workgroup": (8193, 16384), "global": (16385, 1 << 30)}
+
+
+@pytest.mark.parametrize("n,expect_path", [(5000, "regs_1_wave_16_keys"), (9000, "regs_1_wave_32_keys"), (18000, "regs_2_waves"), (36000, "regs_4_waves"),
+                                           (70000, "lds_workgroup"), (110000, "global")])
 def test_every_sort_path(n, expect_path):
-    """Tiny image, many large splats: per-bin lists of <=1024 (register sort, one wave), <=16384 (128 KiB LDS workgroup), beyond (global memory)."""
+    """Tiny image, many large splats: per-bin lists of <= 1024 keys (k_sort_wave: one wave, <= 16 keys per lane in registers), <= 2048 / 4096 / 8192
+    (k_sort_multi: 1 / 2 / 4 waves, 32 keys per lane, cross-wave stages through LDS), <= 16384 (k_sort_large: 128 KiB LDS workgroup), beyond (the
+    same network in global memory).  Every list of every bin is checked for upstream's order (depth bits, then index), whatever kernel sorted it."""
     import torch
     from gps_gaussian_amd import rasterizer as RZ
     from gps_gaussian_amd import synthetic as S
@@ -226,8 +233,10 @@ def test_every_sort_path(n, expect_path):
     o, oimg, oradii = oracle_render(g, "f32")
     st = RZ.export_state(t["ws"], n, 32, 32, t["cap"])
     rg = st["ranges"].cpu().numpy()
-    longest = int((rg[:, 1] - rg[:, 0]).max())
-    assert {"lds_small": longest <= 1024, "lds_large": 1024 < longest <= 16384, "global": longest > 16384}[expect_path], longest
+    lengths = (rg[:, 1] - rg[:, 0]).astype(np.int64)
+    longest = int(lengths.max())
+    lo, hi = _SORT_CLASSES[expect_path]
+    assert ((lengths >= lo) & (lengths <= hi)).any(), (expect_path, sorted(lengths.tolist()))
     np.testing.assert_array_equal(radii, oradii)
     depth_bits = o.geom()["depth"].astype(np.float32).view(np.uint32).astype(np.int64)
     plist = st["point_list"].cpu().numpy().astype(np.int64)

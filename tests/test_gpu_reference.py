@@ -294,3 +294,42 @@ def test_launcher_world_1_with_the_real_networks(tmp_path):
     t = json.load(open(tfile))
     for k in ("network_forward", "pts2render", "loss_l1", "loss_ssim", "backward", "optimizer_step"):
         assert len(t[k]) == 5 and min(t[k]) > 0, (k, t[k])
+
+
+def test_train_stage2_reaches_the_fused_kernels_through_the_import_hook(tmp_path):
+    """train_stage2.py as __main__, UNMODIFIED, twice with the same seeds: plain, and with GPSGS_ACCELERATE=all (gps-gaussian_amd/accelerate.py: the
+    opt-in import hook rebinds pts2render / l1_loss / ssim / CorrBlockFast1D / upsample_flow / flow2depth / depth2pc to the fused kernels of SURVEY
+    section 8(f) as the reference's modules load).  Every replacement must have RUN (call counters), the per-iteration losses the reference logs must
+    agree, the final weights too, and `Trainer.run_eval` (train_stage2.py:103-139: eval-mode model -> pts2render under no_grad -> psnr -> cv2.imwrite)
+    runs inside both (eval_freq 3)."""
+    import torch
+    common = ["train", "--res", "256", "--steps", "6", "--batch", "2", "--train-samples", "2", "--eval-freq", "3"]
+    plain = _tool([os.path.join(ROOT, "tools", "run_reference.py")] + common + ["--work", str(tmp_path / "plain")])
+    fused = _tool([os.path.join(ROOT, "tools", "run_reference.py")] + common + ["--work", str(tmp_path / "fused"), "--accelerate", "all"])
+    assert plain["accelerate"]["rebound"] == [] and plain["accelerate"]["calls"] == {}
+    acc = fused["accelerate"]
+    for name in ("lib.GaussianRender.pts2render", "lib.loss.l1_loss", "lib.loss.ssim", "core.corr.CorrBlockFast1D", "core.raft_stereo_human.CorrBlockFast1D",
+                 "core.raft_stereo_human.FlowUpdateModule.upsample_flow", "lib.utils.flow2depth", "lib.utils.depth2pc"):
+        assert name in acc["rebound"], (name, acc["rebound"])
+    # 6 training iterations + 1 validation batch at step 3: pts2render 7x; l1_loss + ssim 6x each; flow2depth twice per model forward; the convex upsample once per
+    # GRU iteration in training (3 iterations: raft.train_iters) and once per validation forward
+    assert acc["calls"]["pack"] == 7 and acc["calls"]["loss"] == 12 and acc["calls"]["unproject"] == 14 and acc["calls"]["upsample"] >= 6 * 3 + 1, acc["calls"]
+    assert acc["calls"]["corr"] == 7, acc["calls"]   # one correlation block per model forward
+    for r in (plain, fused):
+        assert r["total_steps"] == 6 and r["finite_weights"] and len(r["metrics"]) == 6 and len(r["evals"]) == 1 and r["evals"][0]["val_psnr"] > 0, r
+    worst = {}
+    for a, b in zip(plain["metrics"], fused["metrics"]):
+        for k in ("l1", "ssim", "train_epe"):
+            worst[k] = max(worst.get(k, 0.0), abs(a[k] - b[k]) / max(abs(a[k]), 1e-6))
+    wa = torch.load(plain["final_checkpoint"], map_location="cpu")["network"]
+    wb = torch.load(fused["final_checkpoint"], map_location="cpu")["network"]
+    num = sum(float(((wa[k].double() - wb[k].double()) ** 2).sum()) for k in wa if wa[k].is_floating_point())
+    den = sum(float((wa[k].double() ** 2).sum()) for k in wa if wa[k].is_floating_point())
+    rel_w = (num / den) ** 0.5
+    print({"worst_relative_loss_difference": worst, "relative_weight_difference": rel_w, "psnr": (plain["evals"][0]["val_psnr"], fused["evals"][0]["val_psnr"]),
+           "optimizer_steps": (plain["optimizer_steps"], fused["optimizer_steps"]), "calls": acc["calls"]})
+    # AMP (fp16 feature maps, fp16 correlation volumes) on both sides; the fused volume accumulates in fp32 on the matrix cores where the eager einsum rounds
+    # through fp16, and the fused SSIM sums in a different order: the logged losses agree to ~1e-4 relative, the flow error to ~1e-3
+    assert worst["l1"] < 5e-4 and worst["ssim"] < 5e-4 and worst["train_epe"] < 5e-3, worst
+    assert plain["optimizer_steps"] == fused["optimizer_steps"] and rel_w < 1e-3, (rel_w, plain["optimizer_steps"], fused["optimizer_steps"])
+    assert abs(plain["evals"][0]["val_psnr"] - fused["evals"][0]["val_psnr"]) < 0.05

@@ -68,6 +68,14 @@ class _Clock:
         return {k: (round(sum(a.elapsed_time(b) for a, b in v[skip:]) / max(1, len(v[skip:])), 3), len(v[skip:])) for k, v in self.spans.items()}
 
 
+def _accel_report():
+    """What the opt-in hook rebound in this process and how often each replacement ran ({} when GPSGS_ACCELERATE is unset: the module is not even imported)."""
+    acc = sys.modules.get("gps_gaussian_amd.accelerate")
+    if acc is None:
+        return {"requested": os.environ.get("GPSGS_ACCELERATE", ""), "rebound": [], "calls": {}}
+    return {"requested": os.environ.get("GPSGS_ACCELERATE", ""), "rebound": sorted(acc.installed()), "calls": dict(acc.calls)}
+
+
 def interp(args):
     import numpy as np
     import torch
@@ -156,11 +164,14 @@ def interp(args):
     tot = clk.totals(skip=1)
     RZ._forward_impl = real_fwd
     out["gpu_ms_per_view"] = {k: v[0] for k, v in tot.items()}
-    out["gpu_ms_per_view"]["pack_inside_pts2render"] = round(tot["pts2render"][0] - tot["render"][0], 3)
+    if "render" in tot:  # (with GPSGS_ACCELERATE=pack the reference's render() is not on the path: pts2render is the fused pack + batch node)
+        out["gpu_ms_per_view"]["pack_inside_pts2render"] = round(tot["pts2render"][0] - tot["render"][0], 3)
     out["gaussians_per_view"] = {"mean": int(np.mean(Ps)), "min": int(min(Ps)), "max": int(max(Ps))}
     gpu_ms = tot["network"][0] + tot["pts2render"][0]
     out["views_per_s_gpu_side"] = round(1e3 / gpu_ms, 2)
-    out["raster_share_of_gpu_time"] = round(tot["render"][0] / gpu_ms, 4)
+    if "render" in tot:
+        out["raster_share_of_gpu_time"] = round(tot["render"][0] / gpu_ms, 4)
+    out["accelerate"] = _accel_report()
     img = None
     try:
         from PIL import Image
@@ -244,11 +255,28 @@ def train(args):
         stamps.append(time.perf_counter())
         return real_step(self, *a, **k)
     torch.optim.AdamW.step = step
+    # the per-iteration metrics the reference's own loop hands to its Logger (train_stage2.py:78-82: l1, ssim, train_epe ...), unrounded
+    import lib.train_recoder as TR
+    pushed = []
+    real_push = TR.Logger.push
+
+    def push(self, metrics):
+        pushed.append({k: float(v) for k, v in metrics.items()})
+        return real_push(self, metrics)
+    TR.Logger.push = push
+    evals = []
+    real_write = TR.Logger.write_dict
+
+    def write_dict(self, results, write_step):
+        evals.append({"step": int(write_step), **{k: float(v) for k, v in results.items()}})
+        return real_write(self, results, write_step)
+    TR.Logger.write_dict = write_dict
     t0 = time.perf_counter()
     runpy.run_path(refenv.script(ref, "train_stage2"), run_name="__main__")
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     torch.optim.AdamW.step = real_step
+    TR.Logger.push, TR.Logger.write_dict = real_push, real_write
     n = len(stamps)
     tail = stamps[n // 2:]
     exp = os.path.join(work, "experiments")
@@ -256,7 +284,8 @@ def train(args):
     out = {"mode": "train", "reference": ref, "script": os.path.basename(refenv.script(ref, "train_stage2")), "res": args.res, "batch": args.batch,
            "optimizer_steps": n, "wall_s": round(wall, 2),
            "iters_per_s_second_half": round((len(tail) - 1) / (tail[-1] - tail[0]), 3) if len(tail) > 1 else None,
-           "final_checkpoint_written": bool(ck)}
+           "final_checkpoint_written": bool(ck), "metrics": pushed, "evals": evals, "accelerate": _accel_report(),
+           "final_checkpoint": ck[-1] if ck else None}
     if ck:
         sd = torch.load(ck[-1], map_location="cpu")
         out["finite_weights"] = bool(all(torch.isfinite(v).all() for v in sd["network"].values() if v.is_floating_point()))
@@ -295,7 +324,7 @@ def ddp(args):
     out = {"mode": "ddp", "reference": ref, "res": args.res, "render": "%dx%d" % (2 * args.res, 2 * args.res), "batch_per_gpu": args.batch, "world_size": line["world_size"],
            "steps": line["steps"], "backend": line["backend"], "exchange": line["exchange"],
            "iter_ms_median_second_half": med(t["iter_ms"]), "iters_per_s": round(1e3 / med(t["iter_ms"]), 3),
-           "gpu_ms_per_iter": {k: med(v) for k, v in t.items() if k != "iter_ms"},
+           "gpu_ms_per_iter": {k: med(v) for k, v in t.items() if k != "iter_ms"}, "accelerate": _accel_report(),
            "note": "iter_ms = host time between optimizer steps (includes the DataLoader and the reference's per-iteration .item() syncs); gpu_ms_per_iter = "
                    "hipEvent spans around the reference's own calls: network_forward = RtStereoHumanModel (RAFT-Stereo + regressor, AMP), pts2render = the "
                    "reference's per-sample mask gathers + render() -> HIP rasteriser forward, loss_* = lib/loss.py, backward = autograd incl. the HIP rasteriser backward"}
@@ -318,7 +347,11 @@ def main():
     ap.add_argument("--eval-freq", type=int, default=0)
     ap.add_argument("--write-images", action="store_true")
     ap.add_argument("--ratio", type=float, default=0.5, help="real: position of the novel camera between the two source cameras")
+    ap.add_argument("--accelerate", default=None, help="value for GPSGS_ACCELERATE (gps-gaussian_amd/accelerate.py: e.g. 'all' or 'pack,loss'): the opt-in "
+                                                       "import hook that lets the UNMODIFIED script reach the fused pack / loss / corr / upsample / unproject kernels")
     args = ap.parse_args()
+    if args.accelerate is not None:
+        os.environ["GPSGS_ACCELERATE"] = args.accelerate   # read by the drop-in shims when the reference imports them
     return {"interp": interp, "real": real, "train": train, "ddp": ddp}[args.mode](args)
 
 

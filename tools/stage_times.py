@@ -14,10 +14,11 @@ ap.add_argument("--render-res", type=int, default=None)
 ap.add_argument("--gaussians", type=int, default=600000)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--attributes", default="trained", help="'untrained': scales at the 0.01 m clamp, opacity ~0.5 (what random network weights give: configs 3 / 4)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 rr = a.render_res or a.res
-smp = S.make_stereo_sample(a.res, a.gaussians, seed=S.SEED, render_res=rr)
+smp = S.make_stereo_sample(a.res, a.gaussians, seed=S.SEED, render_res=rr, attributes=a.attributes)
 g = S.compact_sample(smp); cam = smp["novel_view"]
 names = ("means3D", "colors", "opacities", "scales", "rotations")
 t = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in names}
