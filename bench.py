@@ -89,7 +89,15 @@ def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, st
     if not ok_all:
         return {"error": err or "another rank failed"}
     el = timed(step, steps, 2)
-    return {"iters_per_s": round(steps / el, 2), "stereo_pairs_per_s": round(world * batch * steps / el, 1), "ms_per_iter": round(el / steps * 1e3, 3),
+    # the exchange step ALONE (the same 20.6 MB mean all-reduce, nothing around it): what the collective costs at this world size
+    ar_ms = None
+    if dist.is_initialized():
+        try:
+            el_ar = timed(reducer, 10, 2)
+            ar_ms = round(el_ar / 10 * 1e3, 3)
+        except Exception:  # noqa: BLE001
+            ar_ms = None
+    return {"iters_per_s": round(steps / el, 2), "allreduce_alone_ms": ar_ms, "stereo_pairs_per_s": round(world * batch * steps / el, 1), "ms_per_iter": round(el / steps * 1e3, 3),
             "batch_per_gpu": batch, "n_gpus": world, "render": "%dx%d" % (rres, rres),
             "allreduce": ("%s, world %d%s" % (dist.get_backend(), dist.get_world_size(), " (forced: GPSGS_DIST_FORCE=1)" if D.forced() and world == 1 else "")
                           if dist.is_initialized() else "none (one rank, no process group)"),
@@ -97,16 +105,18 @@ def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, st
                         "20.6 MB of network gradients (RCCL); networks not executed" % batch}
 
 
-def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed):
+def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed, attributes="trained", stage_table=False):
     """Secondary measurement (never part of `value`): another BASELINE workload through the same C-ABI sessions as the headline --
-    forward + backward and forward only (inference workspace), one view at a time and `inflight` views in flight, `steps` steps each."""
+    forward + backward and forward only (inference workspace), one view at a time and `inflight` views in flight, `steps` steps each.
+    stage_table: also a per-kernel table (hipEvents around every kernel, one view at a time) with each kernel's algorithmic HBM fraction."""
     import torch
+    from gps_gaussian_amd import _capi
     from gps_gaussian_amd import rasterizer as RZ
     from gps_gaussian_amd import synthetic as S
     from gps_gaussian_amd.session import RasterSession
     names = ("means3D", "colors", "opacities", "scales", "rotations")
     lanes = []
-    smp = S.make_stereo_sample(res, gaussians, seed=S.SEED + 77, render_res=render_res)  # one synthetic view; every lane renders its own copy of it
+    smp = S.make_stereo_sample(res, gaussians, seed=S.SEED + 77, render_res=render_res, attributes=attributes)  # one synthetic view; every lane renders its own copy of it
     g, cam = S.compact_sample(smp), smp["novel_view"]
     for i in range(inflight):
         t = {k: torch.from_numpy(g[k]).to(dev) for k in names}
@@ -140,7 +150,93 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
             out[label][nl] = {"views_per_s": round(steps / el, 1), "ms_per_view": round(el / steps * 1e3, 4),
                               "blocks_ms_per_view": [round(x / steps * 1e3, 4) for x in els],
                               "workspace_reallocations_while_timed": sum(L[kind].allocations for L in lanes) - allocs0}
-    out["R"] = int(RZ.last_stats(dev).get("last_R", 0))
+    out["R"] = R = int(RZ.last_stats(dev).get("last_R", 0))
+    if stage_table:
+        # per-kernel durations of THIS workload, one view at a time (every launch has the chip to itself), and each kernel's algorithmic HBM
+        # fraction (same byte formulas as the headline's `stages`; R = this view's measured instance count)
+        P = out["P"]
+        NB = (((render_res + 7) // 8 + 3) // 4 * 4) * ((render_res + 7) // 8)
+        npix = render_res * render_res
+        alg = {"preprocess": 116 * P, "scan": 8 * NB, "scatter": 24 * P + 12 * R, "sort": 12 * R + 8 * NB, "composite_fwd": 40 * R + 8 * NB + 20 * npix,
+               "composite_bwd": 40 * R + 8 * NB + 20 * npix + 44 * P, "preprocess_bwd": 212 * P}
+        RZ.set_stage_timing(True)
+        run("train", 1, 3)
+        torch.cuda.synchronize(dev)
+        _capi.timing_read()
+        run("train", 1, max(10, steps))
+        st = _capi.timing_read()
+        RZ.set_stage_timing(False)
+        tab = {}
+        for k, (ms, n) in st.items():
+            if n:
+                us = ms / n * 1e3
+                tab[k] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": alg[k], "hbm_frac": round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+        out["stages_one_view_in_flight"] = tab
+        out["stages_sum_us"] = round(sum(v["avg_us"] for v in tab.values()), 1)
+        out["longest_bin_list"] = int(RZ._dev_state(dev).get("longest", 0))
+    return out
+
+
+def full_pipeline_leg(budget_s):
+    """BASELINE configs 3 and 4 at full size, measured in THIS run: the reference's unmodified test_view_interp.py / train_stage2.Trainer (the bytecode build
+    oracle/stage_ref.py leaves in oracle/_ref; /root/reference is never read on the GPU box) with its real networks (random weights) on the drop-in
+    kernels, each once as the reference runs it and once with GPSGS_ACCELERATE=all (the opt-in import hook that lets the unmodified scripts reach the
+    fused pack / loss / corr / upsample / unproject kernels).  MIOpen's exhaustive convolution search takes ~5 minutes on a fresh box, so the children
+    run with MIOPEN_FIND_MODE=FAST (unless the caller set one): the networks are then ~15 % slower than with the default find mode -- the builder's
+    default-find-mode numbers are replayed next to these, labelled.  Anything that does not fit the time budget is skipped and says so."""
+    import subprocess
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import refenv
+        ref = refenv.reference_dir()
+    except Exception as e:  # noqa: BLE001
+        return {"measured_in_this_run": False, "skipped": "tools/refenv.py unavailable: %r" % (e,)}
+    if ref is None:
+        return {"measured_in_this_run": False, "skipped": "no reference build (oracle/_ref/GPS-Gaussian is staged by __graft_entry__.build() where /root/reference exists)"}
+    env = dict(os.environ)
+    env.setdefault("MIOPEN_FIND_MODE", "FAST")
+    env.pop("GPSGS_ACCELERATE", None)
+    t_end = time.perf_counter() + budget_s
+    out = {"measured_in_this_run": True, "miopen_find_mode": env["MIOPEN_FIND_MODE"], "reference": os.path.relpath(ref, ROOT) if ref.startswith(ROOT) else ref,
+           "weights": "random (no checkpoint offline): the regressed scales sit at their 0.01 m clamp, ~3e7 (Gaussian, bin) instances per 2048^2 view",
+           "budget_s": budget_s}
+    work = os.environ.get("GPSGS_BENCH_WORK", "/tmp/gpsgs_bench_ref")
+    legs = (("config4_stage2_accelerated", ["ddp", "--res", "1024", "--steps", "16", "--batch", "4", "--train-samples", "4", "--work", work + "_w4", "--accelerate", "all"]),
+            ("config4_stage2_as_the_reference_runs_it", ["ddp", "--res", "1024", "--steps", "12", "--batch", "4", "--train-samples", "4", "--work", work + "_w4"]),
+            ("config3_view_interp_accelerated", ["interp", "--res", "1024", "--samples", "2", "--views", "5", "--work", work + "_w3", "--accelerate", "all"]),
+            ("config3_view_interp_as_the_reference_runs_it", ["interp", "--res", "1024", "--samples", "2", "--views", "5", "--work", work + "_w3"]))
+    for name, argv in legs:
+        left = t_end - time.perf_counter()
+        if left < 45:
+            out[name] = {"measured_in_this_run": False, "skipped": "time budget (%.0f s) used up" % budget_s}
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference.py")] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                               timeout=left, cwd=ROOT, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"measured_in_this_run": False, "error": (r.stderr or r.stdout)[-300:]}
+                continue
+            d = json.loads(lines[-1])
+        except subprocess.TimeoutExpired:
+            out[name] = {"measured_in_this_run": False, "skipped": "did not finish inside the time budget (%.0f s)" % budget_s}
+            continue
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"measured_in_this_run": False, "error": repr(e)[:300]}
+            continue
+        keep = {"measured_in_this_run": True, "wall_s": round(time.perf_counter() - t0, 1), "accelerate": d.get("accelerate", {}).get("requested", ""),
+                "fused_calls": d.get("accelerate", {}).get("calls", {})}
+        if d["mode"] == "ddp":
+            keep.update(stage2_iters_per_s=d["iters_per_s"], iter_ms=d["iter_ms_median_second_half"], gpu_ms_per_iter=d["gpu_ms_per_iter"], batch_per_gpu=d["batch_per_gpu"],
+                        render=d["render"], steps=d["steps"], world_size=d["world_size"])
+        else:
+            keep.update(views_per_s_within_sample=d["script_run"].get("views_per_s_within_sample"), views_per_s_whole_script=d["script_run"]["views_per_s_end_to_end"],
+                        views_per_s_gpu_side=d.get("views_per_s_gpu_side"), gpu_ms_per_view=d.get("gpu_ms_per_view"), gaussians_per_view=d.get("gaussians_per_view"),
+                        render=d["render"], views=d["script_run"]["views"])
+        out[name] = keep
+    out["leg_wall_s"] = round(budget_s - (t_end - time.perf_counter()), 1)
     return out
 
 
@@ -210,6 +306,8 @@ def main():
                     help="skip every secondary leg (autograd module, forward only, deferred check, stage-2 path, HIP graph, CPU rows): with --inflight 1 "
                          "every kernel launch of the run then has the chip to itself (tools/prof_r02.sh profiles that mode for the exclusive durations)")
     ap.add_argument("--graph-leg", action="store_true", help="(internal) time HIP-graph replays of the fwd+bwd step and print one JSON line")
+    ap.add_argument("--no-full-pipeline", action="store_true", help="skip the `full_pipeline` leg (BASELINE configs 3 / 4 with the reference's own scripts and networks)")
+    ap.add_argument("--full-pipeline-budget", type=float, default=600.0, help="seconds the full-pipeline leg may take in total; what does not fit is skipped and says so")
     args = ap.parse_args()
     if args.graph_leg:
         return graph_leg(args)
@@ -255,6 +353,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     D.init(backend=backend, device=dev)  # "nccl" is RCCL on ROCm; no-op at world size 1
+    # one process per GPU, each host-bound in bursts (F streams of launches): every rank on its own slice of the CPUs (its GPU's NUMA node when
+    # sysfs names one); a no-op at world size 1 and with GPSGS_AFFINITY=0
+    cpu_slice = D.set_cpu_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), local_rank)
     _capi.lib()  # fail loudly if the HIP library is missing
 
     # ---- synthetic workload: one stereo pair per rank (different pose per rank), resident in HBM ------------------
@@ -445,8 +546,12 @@ def main():
     # secondary numbers (outside the headline region): the same step through the autograd drop-in module, forward only, and the
     # non-blocking check mode
     el_api = el_fwd = el_def = el_fwd_def = None
+    api_blocks = None
     if not args.headline_only:
-        el_api = timed(fwd_bwd, args.steps, 5)
+        # the reference's plugin API (GaussianRasterizer -> autograd Function), one view at a time: the SAME protocol as `value` -- REPEATS blocks of
+        # exactly --steps steps, the median block is the number, the quartiles are reported (round 3 took ONE 20-step block: 3,102 - 3,612 run to run)
+        api_blocks = sorted(timed(fwd_bwd, args.steps, 5 if i == 0 else 0) for i in range(REPEATS))
+        el_api = api_blocks[REPEATS // 2]
         el_fwd = timed(fwd_only, args.steps, 3)
         os.environ["GPSGS_CHECK"] = "deferred"
         el_def = timed(fwd_bwd, args.steps, 3)
@@ -481,17 +586,30 @@ def main():
             except Exception as e:  # noqa: BLE001
                 configs[cname] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
-
-    # the full pipeline (BASELINE configs 3 / 4: the reference's own scripts and networks on the drop-in) is measured by tools/run_reference.py
-    # in its own gpurun (MIOpen compiles the networks' convolutions for minutes on a fresh box: not something a default bench run can
-    # carry); its tracked result is REPLAYED here, marked as such
-    full_pipeline = None
-    fp_file = os.path.join(ROOT, "profiles", "full_pipeline.json")
-    if rank == 0 and os.path.exists(fp_file):
+        # the regime BASELINE configs 3 / 4 REALLY run in offline (and stage-2 training starts in): freshly initialised regression heads put every
+        # scale at its 0.01 m clamp (lib/gs_parm_network.py:43,76) -- ~25 px splats at 2048^2, ~55 bins per Gaussian, R ~ 3 x 10^7, ~20,000 bins
+        # with lists of 1,000-3,000 entries (profiles/r03_full_pipeline.md).  Synthetic stand-in with the same statistics, per-kernel table included.
         try:
-            full_pipeline = dict(json.load(open(fp_file)), replayed_from="profiles/full_pipeline.json (tools/run_reference.py on an MI355X; profiles/r03_full_pipeline.md)")
+            configs["config3_regime_untrained_heads_2048 (scales at the 0.01 m clamp, opacity ~0.5: what random network weights give)"] = \
+                config_leg(1024, 550000, 2048, dev, 10, 2, rs, timed, attributes="untrained", stage_table=True)
+        except Exception as e:  # noqa: BLE001
+            configs["config3_regime_untrained_heads_2048"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+
+    # ---- the full pipeline: BASELINE configs 3 / 4 with the reference's OWN scripts and networks, MEASURED IN THIS RUN -------------------------
+    # (rank 0, N = 1; the reference build under oracle/_ref is the CALLER of the product here, executed by tools/run_reference.py in child processes)
+    full_pipeline = None
+    if rank == 0 and world == 1 and not args.headline_only and not args.no_full_pipeline and (args.res, args.gaussians, W) == (1024, 600000, 1024):
+        torch.cuda.empty_cache()  # (the default workload only, like `configs`: a small functional run of bench.py does not start full-size networks)
+        full_pipeline = full_pipeline_leg(args.full_pipeline_budget)
+    fp_file = os.path.join(ROOT, "profiles", "full_pipeline.json")
+    if rank == 0 and full_pipeline is not None and os.path.exists(fp_file):
+        try:  # the builder's own measurement of the same scripts with MIOpen's default (exhaustive) find mode, for comparison: labelled as a replay
+            full_pipeline["replayed_default_find_mode"] = dict(json.load(open(fp_file)), measured_in_this_run=False,
+                                                               replayed_from="profiles/full_pipeline.json (tools/run_reference.py on an MI355X, MIOpen default find mode: "
+                                                                             "minutes of search on a fresh box; profiles/r04_full_pipeline.md)")
         except Exception:  # noqa: BLE001
-            full_pipeline = None
+            pass
 
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------------
     NB = (((W + 7) // 8 + 3) // 4 * 4) * ((H + 7) // 8)  # 8x8-pixel bins (one wave64 each), DESIGN.md section 2
@@ -641,6 +759,12 @@ def main():
             "ms_per_step_iqr": [round(q1 / args.steps * 1e3, 4), round(q3 / args.steps * 1e3, 4)],
             "single_view_in_flight_views_per_s": round(world * n_single / el_single, 2),
             "autograd_api_views_per_s": rate(el_api),
+            "autograd_api": ({"views_per_s": rate(el_api), "iqr_views_per_s": [rate(api_blocks[(3 * REPEATS) // 4]), rate(api_blocks[REPEATS // 4])], "blocks": REPEATS,
+                              "protocol": "the reference's own call shape (GaussianRasterizer(raster_settings)(means3D=..., ...) + image.backward(), "
+                                          "gaussian_renderer/__init__.py:51-62), one view at a time, sync capacity check; median of %d blocks of %d steps" % (REPEATS, args.steps)}
+                             if api_blocks else None),
+            "cpu_affinity": ({"rank0_cpus": len(cpu_slice)} if cpu_slice else "not set (one rank, GPSGS_AFFINITY=0, or no sched_setaffinity)"),
+            "not_measured_at_this_world_size": ([] if world == 1 else ["configs", "full_pipeline", "cpu_baseline", "cpu_taichi_splat_port", "hip_graph_replay"]),
             "stage2_gradient_set": s2,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
             "forward_only_views_per_s": rate(el_fwd),

@@ -232,6 +232,20 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, const uint32
         gsr_view_rows(row_range, P, row0, P);  // with a row range P was only the capacity: records behind the view's last Gaussian were never written
     }
     if ((int)(blockIdx.x * GSR_BIN_THREADS) >= P) return;  // workgroup entirely behind the view's last Gaussian (before any barrier: uniform)
+    if (inst_valid) {
+        // training: "no gradient record yet" for every slot of this workgroup's 1024 Gaussians (replaces a cap-byte memset).  Their slots are ONE
+        // contiguous run [gpart[blk], gpart[blk + 1]) -- cleared by the whole workgroup with 16-byte stores.  (Until round 4 every thread cleared
+        // its own Gaussian's run byte by byte: fine for the ~4-cell rects of trained scales, 100 strided byte stores per thread with scales at
+        // their clamp.)
+        const uint32_t s_beg = gpart[blockIdx.x], s_end = (blockIdx.x + 1 < gridDim.x) ? gpart[blockIdx.x + 1] : hdr->num_slots;
+        for (uint32_t k = (s_beg & ~15u) + (uint32_t)threadIdx.x * 16u; k < s_end; k += GSR_BIN_THREADS * 16u) {
+            if (k >= s_beg && k + 16u <= s_end) {
+                *reinterpret_cast<uint4 *>(inst_valid + k) = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                for (uint32_t b = (k > s_beg ? k : s_beg); b < k + 16u && b < s_end; b++) inst_valid[b] = 0;
+            }
+        }
+    }
     uint32_t lo = 0, hi = 0, mask = 0;
     uint64_t key = 0;
     GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
@@ -244,14 +258,11 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, const uint32
         key = ((uint64_t)__float_as_uint(c.y) << 32) | (uint32_t)i;
         if ((hi & 0xffff) > (lo & 0xffff)) {  // listed somewhere
             const uint32_t area = ((hi & 0xffff) - (lo & 0xffff)) * ((hi >> 16) - (lo >> 16));
-            if (area > 32u) {  // rect too large for the cached mask: the predicate k_preprocess counted with, re-evaluated per cell from the
-                               // record and the threshold k_preprocess left in the mask word (never recomputed here: gsr_hit_from_threshold)
+            if (area > 32u) {  // rect too large for the cached mask: the predicate k_preprocess counted with (row intervals, or per cell for
+                               // ill-conditioned conics: gsr_masked_hit), re-evaluated from the record and the threshold k_preprocess left in the
+                               // mask word (never recomputed here: gsr_hit_from_threshold)
                 const float4 a = rec[0], b = rec[1];
                 hit = gsr_hit_from_threshold(a.x, a.y, a.z, a.w, b.x, __uint_as_float(mask));
-            }
-            if (inst_valid) {  // training: "no gradient record yet" for every slot of this Gaussian (replaces a cap-byte memset)
-                const uint32_t s0 = gpart[i >> 10] + goff[i];
-                for (uint32_t k = 0; k < area; k++) inst_valid[s0 + k] = 0;
             }
         }
     }

@@ -191,16 +191,65 @@ __device__ __forceinline__ bool gsr_bin_hit(const GsrHit &h, int bxi, int byi) {
     return gsr_rect_hit(h, X0, X0 + (float)(GSR_BIN - 1), Y0, Y0 + (float)(GSR_BIN - 1));
 }
 
+// ---- LARGE rects (more than 32 cells): one x-interval per bin row instead of a test per cell ------------------------------------------
+// With freshly initialised networks (BASELINE configs 3 / 4 offline, and the first iterations of stage-2 training) every scale sits at its 0.01 m
+// clamp: ~100-cell rects, ~55 hits per Gaussian, 3 x 10^7 instances per 2048^2 view, and the per-cell test above (~45 VALU instructions, evaluated
+// by the count AND the scatter pass) made k_preprocess / k_scatter 160 / 215 us there (28 / 16 at config 2).  {q <= thr} is convex, so inside
+// the band of pixel rows [Y0, Y0 + 7] of one bin row its x-projection is ONE interval [xl, xr]: the extreme points are those of the ellipse
+// (at dy = -+kk) clamped into the band, where x = x0 - (B/A) dy +- sqrt(A thr - det dy^2) / A.  A cell [X0, X0 + 7] is listed iff it overlaps
+// [xl - 1/4, xr + 1/4]: two square roots per ROW, then a count per cell.  This is NOT the same predicate bit for bit as gsr_rect_hit (it lists
+// a superset: the quarter pixel, and thr is already inflated by 0.2 % + 0.02, four orders of magnitude above the rounding of the discriminant);
+// extra pairs are harmless (the compositor skips them with alpha < 1/255), dropped ones would not be.  What matters is that the COUNT pass
+// (k_preprocess) and the SCATTER pass (k_scatter) take identical decisions: both evaluate this very function on the stored record + the stored
+// threshold, with IEEE +,-,*,/,sqrt,min,max only (both translation units: -ffp-contract=off, correctly rounded divide / sqrt; no libm call).
+// Ill-conditioned conics (det < 1 % of A C: needle-shaped splats, where det itself cancels) keep the per-cell test.
+struct GsrRowSpan {
+    float x, y, BA, rA, AT, det, kk;
+    int ok;
+};
+__device__ __forceinline__ GsrRowSpan gsr_rows_setup(const GsrHit &h) {
+    _Pragma("clang fp contract(off)")
+    GsrRowSpan r;
+    r.x = h.x; r.y = h.y; r.rA = h.rA;
+    r.BA = h.B * h.rA;
+    r.AT = h.A * h.thr;
+    const float ac = h.A * h.C;
+    r.det = ac - h.B * h.B;
+    r.ok = (h.A > 0.f && h.C > 0.f && h.thr > 0.f && r.det > 0.f && r.det >= 0.01f * ac) ? 1 : 0;  // (any NaN compares false)
+    r.kk = r.ok ? h.B * sqrtf(h.thr / (h.C * r.det)) : 0.f;  // the ellipse's rightmost point lies at dy = -kk, its leftmost at dy = +kk
+    return r;
+}
+// cells [xa, xb) of bin row byi, clipped to the rect's columns [x0, x1); xa == xb: none
+__device__ __forceinline__ void gsr_row_cells(const GsrRowSpan &r, int byi, int x0, int x1, int &xa, int &xb) {
+    _Pragma("clang fp contract(off)")
+    const float d0 = (float)(byi * GSR_BIN) - r.y, d1 = d0 + (float)(GSR_BIN - 1);
+    const float dyR = fminf(fmaxf(-r.kk, d0), d1), dyL = fminf(fmaxf(r.kk, d0), d1);
+    const float discR = r.AT - r.det * dyR * dyR, discL = r.AT - r.det * dyL * dyL;
+    const float xr = (r.x - r.BA * dyR) + sqrtf(fmaxf(discR, 0.f)) * r.rA + 0.25f;
+    const float xl = (r.x - r.BA * dyL) - sqrtf(fmaxf(discL, 0.f)) * r.rA - 0.25f;
+    // the band misses the (inflated) ellipse iff both discriminants are negative; 8 c + 7 >= xl and 8 c <= xr otherwise
+    const bool some = discR >= 0.f || discL >= 0.f;
+    const int lo = (int)ceilf((xl - (float)(GSR_BIN - 1)) * 0.125f), hi = (int)floorf(xr * 0.125f) + 1;
+    xa = some ? max(lo, x0) : x0;
+    xb = some ? min(hi, x1) : x0;
+    if (xb < xa) xb = xa;
+}
+
 // Bit k of a hit mask = cell k (row-major inside the rect [x0,x1) x [y0,y1)) passed the exact test.  Rects of more than 32
 // cells are not cached: their mask word carries the bits of the test's threshold instead (GsrHit::thr) and their cells are re-tested,
 // with that very threshold, wherever the mask is consumed.
 // hit predicate backed by a cached mask (falls back to the exact test for uncached rects)
 struct GsrMaskedHit {
     GsrHit h;
+    GsrRowSpan rs;
     uint32_t mask;
     int x0, y0, w;
-    bool big;
+    bool big, rows;
+    __device__ __forceinline__ void span(int y, int &xa, int &xb) const {  // the columns of row y worth looking at
+        if (rows) gsr_row_cells(rs, y, xa, xb, xa, xb);
+    }
     __device__ __forceinline__ bool operator()(int x, int y) const {
+        if (rows) return true;  // span() already was the test
         if (big) return gsr_bin_hit(h, x, y);
         return (mask >> ((y - y0) * w + (x - x0))) & 1u;
     }
@@ -211,6 +260,8 @@ __device__ __forceinline__ GsrMaskedHit gsr_masked_hit(const GsrHit &h, uint32_t
     m.x0 = lo & 0xffff; m.y0 = lo >> 16; m.w = (int)(hi & 0xffff) - m.x0;
     const int area = m.w * ((int)(hi >> 16) - m.y0);
     m.big = area > 32;
+    m.rs = gsr_rows_setup(h);
+    m.rows = m.big && m.rs.ok;
     return m;
 }
 
@@ -247,20 +298,26 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
     if (tab && tid < 4) tab[tid] = area > GSR_BLOCK_TAB ? 0xffffffffu : (uint32_t)(tid == 0 ? bx0 : tid == 1 ? by0 : tid == 2 ? bw : bh);
     if (area > GSR_BLOCK_TAB) {  // incoherent input: plain per-instance atomics (uniform branch)
         if (has)
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) {
+            for (int y = y0; y < y1; y++) {
+                int xa = x0, xb = x1;
+                hit.span(y, xa, xb);
+                for (int x = xa; x < xb; x++) {
                     if (!hit(x, y)) continue;
                     const uint32_t pos = reserve(y * bx + x, 1u);
                     if (EMIT) emit(pos, (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
                 }
+            }
         return;
     }
     for (int t = tid; t < area; t += GSR_BIN_THREADS) s_cnt[t] = 0u;
     __syncthreads();
     if (has)
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++)
+        for (int y = y0; y < y1; y++) {
+            int xa = x0, xb = x1;
+            hit.span(y, xa, xb);
+            for (int x = xa; x < xb; x++)
                 if (hit(x, y)) atomicAdd(&s_cnt[(y - by0) * bw + (x - bx0)], 1u);
+        }
     __syncthreads();
     for (int t = tid; t < area; t += GSR_BIN_THREADS) {
         const uint32_t c = s_cnt[t];
@@ -274,12 +331,15 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
     if (!EMIT) return;
     __syncthreads();
     if (has)
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
+        for (int y = y0; y < y1; y++) {
+            int xa = x0, xb = x1;
+            hit.span(y, xa, xb);
+            for (int x = xa; x < xb; x++) {
                 if (!hit(x, y)) continue;
                 const int t = (y - by0) * bw + (x - bx0);
                 emit(s_base[t] + atomicAdd(&s_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
             }
+        }
 }
 // Scatter pass from the recorded table: no bounding-box reduction, no table clearing, no counting loop -- one barrier.
 template <typename Hit, typename Reserve, typename Emit>
@@ -305,12 +365,15 @@ __device__ __forceinline__ void gsr_block_emit(const uint32_t *tab, uint32_t lo,
     __syncthreads();
     const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
     if ((x1 > x0) && (y1 > y0))
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
+        for (int y = y0; y < y1; y++) {
+            int xa = x0, xb = x1;
+            hit.span(y, xa, xb);
+            for (int x = xa; x < xb; x++) {
                 if (!hit(x, y)) continue;
                 const int t = (y - by0) * bw + (x - bx0);
                 emit(e_base[t] + atomicAdd(&e_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
             }
+        }
 }
 #endif
 

@@ -88,6 +88,27 @@ __device__ __forceinline__ void cov2d(const Ewa &e, const float c6[6], float &a,
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// The (Gaussian, bin) predicate of the COUNT pass: small rects (<= 32 cells) are tested per cell and the outcomes kept as a bit mask for k_scatter;
+// large rects go by row intervals (gsr_row_cells) when the conic allows, per cell otherwise -- k_scatter re-derives either from the record
+// and the threshold stored in the mask word (gsr_masked_hit).
+struct CountHit {
+    GsrHit h;
+    GsrRowSpan rs;
+    uint32_t *mask;
+    int x0, y0, w;
+    bool rows;
+    __device__ __forceinline__ void span(int y, int &xa, int &xb) const {
+        if (rows) gsr_row_cells(rs, y, xa, xb, xa, xb);
+    }
+    __device__ __forceinline__ bool operator()(int x, int y) const {
+        if (rows) return true;
+        const bool hh = gsr_bin_hit(h, x, y);
+        const int k = (y - y0) * w + (x - x0);
+        if (hh && k < 32) *mask |= 1u << k;
+        return hh;
+    }
+};
+
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint32_t *__restrict__ hitmask,
                                                                uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_count,
                                                                GsrHeader *__restrict__ hdr) {
@@ -223,15 +244,13 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     // the exact ellipse/bin test of every cell of the rect is evaluated ONCE, here; the outcomes are kept as a bit mask
     // (cell k = row-major index inside the rect) that k_scatter reuses instead of re-testing every cell twice
     uint32_t mask = 0u;
-    const int mx0 = rlo & 0xffff, my0 = rlo >> 16, mw = (int)(rhi & 0xffff) - mx0;
+    CountHit ch;
+    ch.h = hit; ch.mask = &mask;
+    ch.x0 = rlo & 0xffff; ch.y0 = rlo >> 16; ch.w = (int)(rhi & 0xffff) - ch.x0;
+    ch.rs = gsr_rows_setup(hit);
+    ch.rows = ch.rs.ok && ch.w * ((int)(rhi >> 16) - ch.y0) > 32;  // the rule of gsr_masked_hit(): k_scatter decides with the same numbers
     gsr_block_bin<false>(
-        rlo, rhi, q.bx,
-        [&](int x, int y) {
-            const bool h = gsr_bin_hit(hit, x, y);
-            const int k = (y - my0) * mw + (x - mx0);
-            if (h && k < 32) mask |= 1u << k;
-            return h;
-        },
+        rlo, rhi, q.bx, ch,
         [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t, uint32_t) {},
         wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS);
     // rects of more than 32 cells are not cached: k_scatter re-tests their cells, with THIS threshold (see gsr_hit_from_threshold)
@@ -270,6 +289,31 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const uint32_t gbase = gpart[gb];
         const uint32_t s0 = gbase + goff[i];
         const uint32_t s1 = ((i & 1023) != 1023 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * 1024 < q.P ? gpart[gb + 1] : hdr->num_slots);
+        if (s1 - s0 > 16u) {
+            // LARGE rects (scales at their clamp: ~100 slots per Gaussian, of which the compositing backward wrote a handful -- the splat is hidden
+            // in most of its bins): read 16 FLAGS per step, all in flight together, then fetch only the records that exist, in slot order (the same
+            // summation order as below: bit-identical sums).  The unconditional form below moved 37 bytes for every slot: 2 GB and 1.4 ms per view
+            // in BASELINE config 4 with random weights (profiles/r04_config4_kernel_stats.md), 95 % of it records nobody had written.
+            for (uint32_t sl = s0; sl < s1; sl += 16) {
+                uint32_t m = 0u;
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const uint32_t ri = min(sl + u, s1 - 1u);
+                    m |= (inst_valid[ri] != 0 && sl + u < s1) ? (1u << u) : 0u;
+                }
+                while (m) {
+                    const int u = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t ri = sl + (uint32_t)u;
+                    const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri);
+                    const float4 b0 = r[0], b1 = r[1];
+                    const float b2 = inst_dop[ri];
+                    g0.x += b0.x; g0.y += b0.y; g0.z += b0.z; g0.w += b0.w;
+                    g1.x += b1.x; g1.y += b1.y; g1.z += b1.z; g1.w += b1.w;
+                    g2x += b2;
+                }
+            }
+        } else
         for (uint32_t sl = s0; sl < s1; sl += 4) {
             // 4 slots per step, branch-free: every load is unconditional (index clamped to this Gaussian's last slot) so that all 4
             // flag and 12 record loads are in flight together; what does not exist is dropped by a SELECT afterwards (never a

@@ -23,8 +23,11 @@ def forced():
     return os.environ.get("GPSGS_DIST_FORCE") == "1"
 
 
-def init(backend=None, device=None):
-    """Initialise the default process group from the torchrun environment.  Returns (rank, local_rank, world)."""
+def init(backend=None, device=None, timeout_s=None):
+    """Initialise the default process group from the torchrun environment.  Returns (rank, local_rank, world).
+    timeout_s: the collectives' watchdog timeout, set EXPLICITLY (default: $GPSGS_PG_TIMEOUT_S, else 1800 s) -- rank 0 of the stage-2 launcher
+    evaluates a validation set while the other ranks wait for it (tools/launch_stage2.py), which must not look like a hang."""
+    import datetime
     rank, local_rank, world = env_rank()
     if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -34,8 +37,58 @@ def init(backend=None, device=None):
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("GPSGS_PG_TIMEOUT_S", "1800"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, local_rank, world
+
+
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(device_index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs: /sys/bus/pci/devices/<bdf>/numa_node -> /sys/devices/system/node/node<n>/cpulist), or None
+    when the platform does not say (numa_node = -1, no sysfs, no PCI ids from the runtime)."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return None
+        return _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def set_cpu_affinity(local_rank, local_world, device_index=None):
+    """One process per GPU, and every process is host-bound in bursts (six HIP streams of launches per rank in bench.py, the DataLoader workers of
+    the trainer): pin each rank to its own slice of the CPUs -- those of its GPU's NUMA node when sysfs names one, else an even split of whatever
+    this process may run on -- so that 8 ranks do not migrate across sockets or pile onto the same cores.  GPSGS_AFFINITY=0 switches it off.
+    Returns the CPU set chosen (or None: left alone)."""
+    if os.environ.get("GPSGS_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        node = gpu_numa_cpus(device_index) if device_index is not None else None
+        pool = sorted(set(allowed) & node) if node else allowed
+        # ranks that share a pool (same NUMA node, or no topology information: everybody) split it evenly, in local-rank order
+        sharers, me = local_world, local_rank
+        if node:
+            same = [r for r in range(local_world) if (gpu_numa_cpus(r) or set()) == node]
+            sharers, me = max(1, len(same)), (same.index(local_rank) if local_rank in same else 0)
+        per = max(1, len(pool) // sharers)
+        mine = pool[me * per:(me + 1) * per] or pool
+        os.sched_setaffinity(0, mine)
+        return set(mine)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def shutdown():
@@ -68,15 +121,25 @@ def shard_views(n_views, rank, world):
 class GradAllReducer:
     """Bucketed mean all-reduce of parameter gradients (the only exchange step of stage-2 training).
 
-    The model has 5,144,408 fp32 parameters = 20.6 MB: with the default 32 MiB bucket that is ONE
-    collective per step -- xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce is per-link bound, so fewer and
-    larger messages win.  Parameters that received no gradient (the reference constructs but never uses gru16/gru32,
-    core/update.py:105-106) are treated as zeros so that every rank issues identical collectives."""
+    The model has 5,144,408 fp32 parameters = 20.6 MB.  Two ways to run it:
+      * overlap=False: everything after the backward -- `reducer()` flattens each bucket, all-reduces it, writes the mean back.  With the default
+        32 MiB bucket that is ONE collective per step (xGMI is point-to-point, 7 links x ~153 GB/s, a ring all-reduce is per-link bound: fewer and
+        larger messages win) -- and it is serial behind the whole backward.
+      * overlap=True: the buckets are filled in REVERSE parameter order (the order autograd produces gradients in) and a post-accumulate hook on
+        every parameter launches a bucket's all-reduce on a side stream the moment its last gradient exists, while the backward of the earlier
+        layers is still running; `reducer()` then only launches what the hooks could not (buckets holding parameters that received no gradient:
+        the reference constructs but never uses gru16 / gru32, core/update.py:105-106 -- they travel as zeros, so every rank issues identical
+        collectives), waits, and writes the means back.  Smaller buckets (8 MiB: ~3 messages) give the overlap something to start early.
+    Both produce the same numbers (tests/test_multiproc_gloo.py)."""
 
-    def __init__(self, params, bucket_bytes=32 << 20):
+    def __init__(self, params, bucket_bytes=None, overlap=False):
         self.params = [p for p in params if p.requires_grad]
+        self.overlap = bool(overlap)
+        if bucket_bytes is None:
+            bucket_bytes = (8 << 20) if self.overlap else (32 << 20)
+        order = list(reversed(self.params)) if self.overlap else list(self.params)
         self.buckets, cur, size = [], [], 0
-        for p in self.params:
+        for p in order:
             n = p.numel() * p.element_size()
             if cur and size + n > bucket_bytes:
                 self.buckets.append(cur)
@@ -85,15 +148,51 @@ class GradAllReducer:
             size += n
         if cur:
             self.buckets.append(cur)
+        self._ready = [0] * len(self.buckets)
+        self._inflight = {}  # bucket index -> (flat tensor, work handle, event)
+        self._comm = None
+        self._hooks = []
+        if self.overlap:
+            where = {id(p): b for b, bucket in enumerate(self.buckets) for p in bucket}
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda t, b=where[id(p)]: self._on_grad(b)))
+
+    def _active(self):
+        return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+    def _launch(self, b):
+        bucket = self.buckets[b]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        if flat.is_cuda and self.overlap:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=flat.device)
+            cur = torch.cuda.current_stream(flat.device)
+            self._comm.wait_stream(cur)  # the flattened gradients are ready on the compute stream
+            with torch.cuda.stream(self._comm):
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            flat.record_stream(self._comm)
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._inflight[b] = (flat, work)
+
+    def _on_grad(self, b):
+        if not self._active():
+            return
+        self._ready[b] += 1
+        if self._ready[b] == len(self.buckets[b]) and b not in self._inflight:
+            self._launch(b)
 
     @torch.no_grad()
     def __call__(self):
-        if not (dist.is_initialized() and (dist.get_world_size() > 1 or forced())):
+        if not self._active():
             return
         world = dist.get_world_size()
-        for bucket in self.buckets:
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        for b in range(len(self.buckets)):  # whatever the hooks did not start (overlap off; or parameters without a gradient in the bucket)
+            if b not in self._inflight:
+                self._launch(b)
+        for b, bucket in enumerate(self.buckets):
+            flat, work = self._inflight.pop(b)
+            work.wait()  # (CUDA: makes the current stream wait for the collective)
             flat.div_(world)
             off = 0
             for p in bucket:
@@ -102,3 +201,9 @@ class GradAllReducer:
                     p.grad = torch.empty_like(p)
                 p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
+        self._ready = [0] * len(self.buckets)
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -42,6 +42,10 @@ HOOK = textwrap.dedent('''
             self.raft_stereo = _Raft()
             self.head = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 3, 3, padding=1))
         def forward(self, data, is_train=True):
+            prev = len(SEEN) - 1                             # the iteration that just ended (train_stage2.py:92: eval when total_steps % eval_freq == 0)
+            if EVAL_FREQ and prev > 0 and prev % EVAL_FREQ == 0:
+                # rank 0 validated after that iteration; EVERY rank must have waited for it (the launcher's barrier) before starting this one
+                assert os.path.exists(EVAL_MARK % prev), "rank %d ran ahead of rank 0's validation pass" % rank
             SEEN.append(int(data["sample_id"][0]))
             x = torch.cat([data["lmain"]["img"], data["rmain"]["img"]], 0)
             y = self.head(self.raft_stereo.bn(x))
@@ -66,6 +70,17 @@ HOOK = textwrap.dedent('''
         return data
 
     TS.RtStereoHumanModel, TS.StereoHumanDataset, TS.pts2render = TinyModel, ToySet, fake_pts2render
+    EVAL_FREQ = int(os.environ.get("LAUNCH_TEST_EVAL_FREQ", "0"))
+    EVAL_MARK = os.environ["LAUNCH_TEST_OUT"] + ".eval_%d"
+    EVAL_RANKS = []
+
+    def toy_eval(self):                                      # stands in for Trainer.run_eval (train_stage2.py:103-139): slow, and rank 0 only
+        import time
+        EVAL_RANKS.append(rank)
+        time.sleep(0.7)
+        open(EVAL_MARK % self.total_steps, "w").write("done")
+
+    TS.Trainer.run_eval = toy_eval
     real_train = TS.Trainer.train
 
     def train_and_verify(self):
@@ -74,19 +89,20 @@ HOOK = textwrap.dedent('''
         flat = torch.cat([p.detach().reshape(-1) for p in self.model.parameters()])
         moved = float((flat - torch.cat([p.reshape(-1) for p in init])).abs().max())
         both = [None] * world
-        dist.all_gather_object(both, (flat.tolist(), SEEN))
+        dist.all_gather_object(both, (flat.tolist(), SEEN, EVAL_RANKS))
         out = os.environ["LAUNCH_TEST_OUT"]
         if rank == 0:
             json.dump({"identical": both[0][0] == both[1][0], "moved": moved, "seen": [b[1] for b in both], "cfg_global": TS.cfg is cfg,
-                       "steps": int(self.total_steps)}, open(out, "w"))
+                       "steps": int(self.total_steps), "eval_ranks": [b[2] for b in both]}, open(out, "w"))
 
     TS.Trainer.train = train_and_verify
 ''')
 
 
-@pytest.mark.parametrize("form", ["checkout", "staged-bytecode"])
+@pytest.mark.parametrize("form", ["checkout", "staged-bytecode", "checkout-eval-inside-the-run"])
 def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path, form):
     ref = REF
+    eval_freq = 2 if form.endswith("eval-inside-the-run") else 1000
     if form == "staged-bytecode":     # what the GPU box has: oracle/stage_ref.py's build of the reference (sourceless .pyc + YAML)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         try:
@@ -97,14 +113,16 @@ def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path, form):
     hook = tmp_path / "hook.py"
     hook.write_text(HOOK)
     out = tmp_path / "result.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", LAUNCH_TEST_OUT=str(out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", LAUNCH_TEST_OUT=str(out), LAUNCH_TEST_EVAL_FREQ=str(eval_freq if eval_freq < 1000 else 0))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
            os.path.join(ROOT, "tools", "launch_stage2.py"), "--reference", ref, "--backend", "gloo", "--steps", "6", "--exp-root", str(tmp_path / "experiments"),
-           "--hook", str(hook), "stage1_ckpt", "None", "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", "1000"]
+           "--hook", str(hook), "stage1_ckpt", "None", "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", str(eval_freq)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
     res = json.load(open(out))
     assert res["identical"] and res["moved"] > 0 and res["cfg_global"] and res["steps"] == 6
+    # validation inside the run (eval_freq 2: after iterations 2 and 4): rank 0 ran it, rank 1 never did -- and waited for it (the forward's assertion)
+    assert res["eval_ranks"] == ([[0, 0], []] if eval_freq == 2 else [[], []]), res["eval_ranks"]
     s0, s1 = res["seen"]
     assert len(s0) == 6 and len(s1) == 6 and not (set(s0) & set(s1) and s0 == s1)      # different shards
     line = [l for l in r.stdout.splitlines() if l.startswith("{") and "launch_stage2" in l]

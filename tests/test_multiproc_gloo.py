@@ -51,6 +51,35 @@ WORKER = textwrap.dedent("""
         assert torch.allclose(p.grad, want, atol=1e-6)
     for p in unused.parameters():
         assert p.grad is not None and float(p.grad.abs().max()) == 0.0
+    # --- the overlapped form: buckets in reverse parameter order, launched from post-accumulate hooks DURING the backward; same numbers
+    serial = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    red2 = D.GradAllReducer(params, bucket_bytes=300, overlap=True)
+    assert len(red2.buckets) > 1 and red2.buckets[0][0] is params[-1]
+    net(x).sum().backward()
+    started = len(red2._inflight)               # collectives already in flight when backward() returns
+    red2()
+    assert started >= 1 and not red2._inflight
+    for p, want in zip(params, serial):
+        assert p.grad is not None and torch.equal(p.grad, want), (p.shape, (p.grad - want).abs().max())
+    # a second iteration through the same hooks (counters reset by the call)
+    for p in params:
+        p.grad = None
+    net(x).sum().backward()
+    red2()
+    for p, want in zip(params, serial):
+        assert torch.equal(p.grad, want)
+    red2.remove_hooks()
+    # --- CPU affinity helper: every rank gets a non-empty slice of what it may run on; two ranks sharing one pool get disjoint slices when there are >= 2 CPUs
+    before = sorted(os.sched_getaffinity(0))
+    mine = D.set_cpu_affinity(rank, world)
+    slices = [None, None]
+    dist.all_gather_object(slices, sorted(mine) if mine else None)
+    if len(before) >= 2:
+        assert slices[0] and slices[1] and not (set(slices[0]) & set(slices[1])), slices
+        assert sorted(os.sched_getaffinity(0)) == sorted(mine)
+    os.sched_setaffinity(0, before)
     if rank == 0:
         print(json.dumps({"metric": "protocol", "n_gpus": world, "value": 2 / el, "views": allv}))
     D.shutdown()

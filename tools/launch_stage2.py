@@ -120,6 +120,10 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="override cfg.num_steps")
     ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo")
     ap.add_argument("--exp-root", default=None, help="where experiments/<name>/ goes (default: the reference's cwd-relative 'experiments')")
+    ap.add_argument("--no-overlap", action="store_true", help="issue the gradient all-reduce after the whole backward (one 32 MiB bucket) instead of from "
+                                                              "post-accumulate hooks while the backward of the earlier layers is still running (8 MiB buckets)")
+    ap.add_argument("--pg-timeout-s", type=float, default=None, help="watchdog timeout of the collectives (default $GPSGS_PG_TIMEOUT_S, else 1800): must cover rank 0's "
+                                                                     "validation pass, during which the other ranks wait at a barrier")
     ap.add_argument("--hook", default=None, help="python file exec'd after `train_stage2` is imported and before Trainer(cfg) is built, with TS (the "
                                                  "module), cfg, rank, world in scope: synthetic data sets, smoke tests")
     ap.add_argument("overrides", nargs="*", help="KEY VALUE pairs merged into the config (yacs merge_from_list syntax)")
@@ -142,7 +146,9 @@ def main(argv=None):
     if use_cuda:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if use_cuda else None
-    D.init(backend=args.backend, device=dev)  # no-op at world size 1
+    D.init(backend=args.backend, device=dev, timeout_s=args.pg_timeout_s)  # no-op at world size 1
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpus = D.set_cpu_affinity(local_rank, local_world, local_rank if use_cuda else None)  # this rank (and the DataLoader workers it forks) on its own CPU slice
 
     refenv.activate(ref)            # shims if needed; DROPIN_DIR (`import diff_gaussian_rasterization` / `import corr_sampler` -> the MI355X
     assert sys.path[0] == DROPIN_DIR  # kernels) ahead of the reference on sys.path
@@ -211,7 +217,7 @@ def main(argv=None):
     np.random.seed(1314 + 1000 * rank)
 
     # ---- the one exchange step ------------------------------------------------------------------------------------------------------
-    reducer = D.GradAllReducer(trainer.model.parameters())
+    reducer = D.GradAllReducer(trainer.model.parameters(), overlap=not args.no_overlap)
     real_unscale = trainer.scaler.unscale_
 
     def unscale_after_allreduce(optimizer):
@@ -220,9 +226,18 @@ def main(argv=None):
 
     trainer.scaler.unscale_ = unscale_after_allreduce
     timing = _install_timing(TS, trainer, torch) if (args.timing and rank == 0 and use_cuda) else None
+    # validation (train_stage2.py:92-96 -> run_eval) stays on rank 0, like logging and checkpoints -- but every rank passes through it: the others
+    # wait at an EXPLICIT barrier until rank 0 is done, instead of running ahead into the next iteration's all-reduce and sitting in a collective
+    # for as long as the validation set takes (an RCCL watchdog timeout on a real validation set; the barrier is covered by --pg-timeout-s)
+    real_eval = trainer.run_eval
+
+    def eval_then_barrier(*a, **k):
+        out = real_eval(*a, **k) if rank == 0 else None
+        D.barrier(local_rank if use_cuda else None)
+        return out
+    trainer.run_eval = eval_then_barrier
     if rank != 0:
         trainer.save_ckpt = lambda *a, **k: None
-        trainer.run_eval = lambda *a, **k: None
     trainer.train()
     D.barrier(local_rank if use_cuda else None)
     if timing is not None:
@@ -230,7 +245,8 @@ def main(argv=None):
             json.dump(timing(), f)
     if rank == 0:
         print(json.dumps({"launcher": "launch_stage2", "world_size": world, "steps": int(trainer.total_steps), "exchange": "mean all-reduce of %d gradients in %d bucket(s)"
-                          % (sum(p.numel() for p in reducer.params), len(reducer.buckets)), "backend": dist.get_backend() if dist.is_initialized() else None}))
+                          % (sum(p.numel() for p in reducer.params), len(reducer.buckets)), "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "exchange_overlapped_with_backward": bool(reducer.overlap), "cpu_affinity": (len(cpus) if cpus else None)}))
     D.shutdown()
 
 
