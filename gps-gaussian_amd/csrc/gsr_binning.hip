@@ -356,18 +356,29 @@ __device__ __forceinline__ void sort_one_bin(uint64_t *sk, uint32_t off, uint32_
 template <uint32_t LM>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
     const int x = (int)v;
-    if (LM == 1u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    if (LM == 2u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    if (LM == 3u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
-    if (LM == 7u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    if (LM == 15u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); // row_mirror
-    if (LM == 8u) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);  // row_ror:8
+    // (old = 0 with bound_ctrl: every lane of these patterns has a source inside its row, so `old` is never read -- but naming x as `old` made the
+    //  compiler copy x into the destination first: one v_mov_b32 + a DPP hazard s_nop per exchanged word, 897 + 905 of them in k_sort_multi)
+    if (LM == 1u) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    if (LM == 2u) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    if (LM == 3u) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    if (LM == 7u) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    if (LM == 15u) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); // row_mirror
+    if (LM == 8u) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);  // row_ror:8
     if (LM == 4u) {
         const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0, 2: lane <- lane + 4
         return (uint32_t)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);  // row_shr:4 into banks 1, 3: lane <- lane - 4
     }
     return (uint32_t)__shfl_xor(x, (int)LM, 64);
 }
+
+// Order of two keys.  A key is (float bits of a depth > 0.2) << 32 | Gaussian id: read as an IEEE DOUBLE it is a positive, finite, normal number
+// (sign 0; the double's exponent field = the float's exponent + its three top mantissa bits, never all ones for a finite or infinite float depth; NaN
+// depths are culled by k_preprocess), and positive doubles order exactly like their bit patterns.  v_cmp_lt_f64 runs at the full vector rate on
+// gfx950; v_cmp_lt_u64 does not -- with one 64-bit integer compare per compare-exchange the sort kernels were bound by it (round 4: k_sort_multi
+// 500 us at 15,000 lists of ~1,700 keys, ~11 cycles per instruction on average).  The padding key is +infinity (0x7FF0...0): above every real
+// key, equal to itself, never NaN.
+constexpr uint64_t SORT_PAD = 0x7FF0000000000000ull;
+__device__ __forceinline__ bool key_lt(uint64_t a, uint64_t b) { return __longlong_as_double((long long)a) < __longlong_as_double((long long)b); }
 
 // one stage of the ascending-only bitonic network (KB = block level, ST = stage inside it; everything a compile-time constant)
 template <int KPL, int KB, int ST>
@@ -383,7 +394,7 @@ __device__ __forceinline__ void sort_stage(uint64_t (&key)[KPL], int lane) {
             const int r2 = r ^ (int)rmask;
             if (r2 > r) {
                 const uint64_t a = key[r], b = key[r2];
-                const bool sw = a > b;
+                const bool sw = key_lt(b, a);
                 key[r] = sw ? b : a;
                 key[r2] = sw ? a : b;
             }
@@ -404,7 +415,7 @@ __device__ __forceinline__ void sort_stage(uint64_t (&key)[KPL], int lane) {
             // lower element of the pair keeps the minimum, upper the maximum.  Keys are unique (equal only among the +inf
             // padding), so "b > a" is "not (b < a)": ONE 64-bit compare whose lane mask is flipped (scalar xor) for the
             // upper lanes -- the select-between-two-compares form compiled to 9 VALU instructions per element
-            const bool take = (b < a) != !lower;
+            const bool take = key_lt(b, a) != !lower;
             key[r] = take ? b : a;
         }
     }
@@ -424,7 +435,7 @@ __device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg,
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const uint32_t e = (uint32_t)lane * KPL + r;
-        key[r] = e < n ? seg[e] : ~0ull;
+        key[r] = e < n ? seg[e] : SORT_PAD;
     }
     sort_stages_from<KPL, LOGN, 1, 0>(key, lane);
 #pragma unroll
@@ -478,7 +489,7 @@ __device__ __forceinline__ void sm_inreg(uint64_t (&key)[SM_KPL]) {
         const int r2 = r ^ RM;
         if (r2 > r) {
             const uint64_t a = key[r], b = key[r2];
-            const bool sw = a > b;
+            const bool sw = key_lt(b, a);
             key[r] = sw ? b : a;
             key[r2] = sw ? a : b;
         }
@@ -494,10 +505,10 @@ __device__ __forceinline__ void sm_cross(uint64_t (&key)[SM_KPL], bool lower) {
         if (r2 < r) continue;
         const uint64_t mine = key[r], mine2 = key[r2];
         const uint64_t got = lane_xor64<LM>(mine2);           // the partner lane's register r2 pairs with my register r
-        key[r] = ((got < mine) != !lower) ? got : mine;       // keys are unique: one compare, flipped for the upper lane (see sort_stage)
+        key[r] = (key_lt(got, mine) != !lower) ? got : mine;  // keys are unique: one compare, flipped for the upper lane (see sort_stage)
         if (r2 != r) {
             const uint64_t got2 = lane_xor64<LM>(mine);
-            key[r2] = ((got2 < mine2) != !lower) ? got2 : mine2;
+            key[r2] = (key_lt(got2, mine2) != !lower) ? got2 : mine2;
         }
     }
 }
@@ -552,13 +563,13 @@ __device__ __forceinline__ void sm_lds_stage(uint64_t (&key)[SM_KPL], uint64_t *
 #pragma unroll
         for (int r = 0; r < SM_KPL; r++) {
             const uint64_t got = xch[r * T + tp], mine = key[r];
-            key[r] = ((got < mine) != !lower) ? got : mine;
+            key[r] = (key_lt(got, mine) != !lower) ? got : mine;
         }
     } else {  // flip: rm == 31
 #pragma unroll
         for (int r = 0; r < SM_KPL; r++) {
             const uint64_t got = xch[(r ^ (SM_KPL - 1)) * T + tp], mine = key[r];
-            key[r] = ((got < mine) != !lower) ? got : mine;
+            key[r] = (key_lt(got, mine) != !lower) ? got : mine;
         }
     }
 }
@@ -572,7 +583,7 @@ __device__ __forceinline__ void sort_multi(const uint64_t *__restrict__ seg, uin
 #pragma unroll
     for (int r = 0; r < SM_KPL; r++) {
         const uint32_t e = (uint32_t)(r * T + t);  // any assignment of the unsorted keys to elements will do: coalesced
-        key[r] = e < n ? seg[e] : ~0ull;
+        key[r] = e < n ? seg[e] : SORT_PAD;
     }
     for (int kb = 1; kb <= LOGN; kb++) {  // merge sorted runs of 2^(kb-1) into runs of 2^kb: one flip, then half-cleaners of stride 2^j
         if (kb <= SM_LOGK) sm_inreg_switch((1u << kb) - 1u, key);
@@ -594,7 +605,7 @@ __device__ __forceinline__ void sort_multi(const uint64_t *__restrict__ seg, uin
 // A persistent grid strides over the BUSY bins in work order (wg_order: the longest lists first, so the stride deals them out evenly) and
 // sorts those whose length falls into this launch's class: (1024 << (NW/2)) < n <= 2048 * NW ... i.e. NW = 1: 1,025-2,048, 2: -4,096, 4: -8,192.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3))) void k_sort_multi(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 2 : 3))) void k_sort_multi(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                         const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                         const GsrHeader *__restrict__ hdr) {
     __shared__ uint64_t xch[NW > 1 ? NW * 64 * SM_KPL : 1];

@@ -315,18 +315,29 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
         for (int y = y0; y < y1; y++) {
             int xa = x0, xb = x1;
             hit.span(y, xa, xb);
+#if defined(GSR_ABL_COUNT_NO_LOOP)  // build-time probes (never defined in a product build): what bounds the count pass with ~100-cell rects?
+            (void)xa; (void)xb;
+#elif defined(GSR_ABL_COUNT_NO_LDS_ATOMIC)
+            for (int x = xa; x < xb; x++)
+                if (hit(x, y)) s_cnt[(y - by0) * bw + (x - bx0)] = 1u;
+#else
             for (int x = xa; x < xb; x++)
                 if (hit(x, y)) atomicAdd(&s_cnt[(y - by0) * bw + (x - bx0)], 1u);
+#endif
         }
     __syncthreads();
     for (int t = tid; t < area; t += GSR_BIN_THREADS) {
         const uint32_t c = s_cnt[t];
         if (tab) tab[4 + t] = c;
+#if defined(GSR_ABL_COUNT_NO_LOOP) || defined(GSR_ABL_COUNT_NO_LDS_ATOMIC) || defined(GSR_ABL_COUNT_NO_GLOBAL_ATOMIC)
+        (void)c;  // probes: no bin ever receives a count, so R = 0 and every later kernel is a no-op (a count / scatter mismatch would corrupt the lists)
+#else
         if (c) {
             const int ty = t / bw, tx = t - ty * bw;
             const uint32_t base = reserve((by0 + ty) * bx + bx0 + tx, c);
             if (EMIT) { s_base[t] = base; s_cnt[t] = 0u; }
         }
+#endif
     }
     if (!EMIT) return;
     __syncthreads();

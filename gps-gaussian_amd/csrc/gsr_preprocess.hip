@@ -291,20 +291,21 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const uint32_t s1 = ((i & 1023) != 1023 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * 1024 < q.P ? gpart[gb + 1] : hdr->num_slots);
         if (s1 - s0 > 16u) {
             // LARGE rects (scales at their clamp: ~100 slots per Gaussian, of which the compositing backward wrote a handful -- the splat is hidden
-            // in most of its bins): read 16 FLAGS per step, all in flight together, then fetch only the records that exist, in slot order (the same
+            // in most of its bins): read 16 FLAGS per step, then fetch only the records that exist, in slot order (the same
             // summation order as below: bit-identical sums).  The unconditional form below moved 37 bytes for every slot: 2 GB and 1.4 ms per view
             // in BASELINE config 4 with random weights (profiles/r04_config4_kernel_stats.md), 95 % of it records nobody had written.
-            for (uint32_t sl = s0; sl < s1; sl += 16) {
-                uint32_t m = 0u;
-#pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    const uint32_t ri = min(sl + u, s1 - 1u);
-                    m |= (inst_valid[ri] != 0 && sl + u < s1) ? (1u << u) : 0u;
-                }
+            // (flags are the bytes 0 / 1; they are read as ALIGNED 16-byte words covering the run -- the section is 256-byte aligned and padded, and
+            //  whatever lies outside [s0, s1) is masked off -- instead of 16 single-byte loads per step: one memory instruction per 16 slots)
+            for (uint32_t base = s0 & ~15u; base < s1; base += 16u) {
+                const uint4 f = *reinterpret_cast<const uint4 *>(inst_valid + base);
+                auto nib = [](uint32_t w) { w &= 0x01010101u; return (w | (w >> 7) | (w >> 14) | (w >> 21)) & 0xFu; };
+                uint32_t m = nib(f.x) | (nib(f.y) << 4) | (nib(f.z) << 8) | (nib(f.w) << 12);
+                const uint32_t lo = s0 > base ? s0 - base : 0u, hi = min(16u, s1 - base);
+                m &= (0xFFFFu >> (16u - hi)) & ~((1u << lo) - 1u);
                 while (m) {
                     const int u = __builtin_ctz(m);
                     m &= m - 1u;
-                    const uint32_t ri = sl + (uint32_t)u;
+                    const uint32_t ri = base + (uint32_t)u;
                     const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri);
                     const float4 b0 = r[0], b1 = r[1];
                     const float b2 = inst_dop[ri];

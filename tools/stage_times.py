@@ -8,6 +8,7 @@ import gps_gaussian_amd  # noqa
 from gps_gaussian_amd import _capi, synthetic as S, rasterizer as RZ
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None, help="development: load this build of libgpsgs_hip.so instead (tools/build_ablations.sh: GSR_ABL_* probe variants)")
 ap.add_argument("--families", default="tiles,valu")
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--render-res", type=int, default=None)
@@ -16,6 +17,8 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--attributes", default="trained", help="'untrained': scales at the 0.01 m clamp, opacity ~0.5 (what random network weights give: configs 3 / 4)")
 a = ap.parse_args()
+if a.lib:
+    _capi.LIB_PATH = os.path.abspath(a.lib)
 dev = torch.device("cuda:0")
 rr = a.render_res or a.res
 smp = S.make_stereo_sample(a.res, a.gaussians, seed=S.SEED, render_res=rr, attributes=a.attributes)
