@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
 SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gpsgs_measure_sclk", "gsr_debug_set_wg_trace", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_selftest", "gsr_timing_read", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
-    "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "cs_forward", "cs_backward",
+    "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "up_unproject_forward_dev", "up_unproject_backward_dev", "cs_forward", "cs_backward",
     "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
 )
 
@@ -105,6 +105,10 @@ def lib():
     l.up_unproject_forward.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
     l.up_unproject_backward.restype = i32
     l.up_unproject_backward.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp]
+    l.up_unproject_forward_dev.restype = i32
+    l.up_unproject_forward_dev.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, vp, vp]
+    l.up_unproject_backward_dev.restype = i32
+    l.up_unproject_backward_dev.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp]
     l.cs_forward.restype = i32
     l.cs_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     l.cs_backward.restype = i32

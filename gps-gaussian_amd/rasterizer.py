@@ -112,21 +112,48 @@ def _check_mode():
 
 
 def _drain_pending(st, block=False):
+    """Look at the capacity results of earlier GPSGS_CHECK=deferred forwards.  Two kinds of entries: ("note", ...) -- the binning scan stores the
+    header straight into a pinned slot ~40 us into the forward (round 4: deferred mode uses the early notification too; until then it copied the
+    header at the END of the forward, so the blocking drain in the backward waited for the whole forward and deferred ran SLOWER than sync) -- and
+    ("ev", ...) -- a header copy + event at the end of the forward (GPSGS_EARLY_NOTIFY=0)."""
     keep = []
-    for ev, hdr, P in st["pending"]:
-        if block:
-            ev.synchronize()
-        if ev.query():
-            R, overflow, need = _decode(hdr)
-            _learn(st, R, need, P if P is not None else int(hdr[3]) & 0xffffffff, (int(hdr[1]) >> 32) & 0xffffffff)
+    pending, st["pending"] = st["pending"], []
+    try:
+        for i, ent in enumerate(pending):
+            if ent[0] == "note":
+                _, (slot, hdr, w32, seq), stream, P, dev_index = ent
+                if int(w32[7]) != seq:
+                    if not block:
+                        keep.append(ent)
+                        continue
+                    try:
+                        _wait_notify(w32, seq, stream)
+                    except Exception:
+                        _rings[(dev_index, "notify")].release(slot)
+                        raise
+                R, overflow, need = _decode(hdr)
+                npts, longest = int(w32[6]), int(w32[3])
+                _rings[(dev_index, "notify")].release(slot)
+                _learn(st, R, need, P if P is not None else npts, longest)
+                if longest > 768:
+                    st["big_bins"] = True
+            else:
+                _, ev, hdr, P = ent
+                if block:
+                    ev.synchronize()
+                if not ev.query():
+                    keep.append(ent)
+                    continue
+                R, overflow, need = _decode(hdr)
+                _learn(st, R, need, P if P is not None else int(hdr[3]) & 0xffffffff, (int(hdr[1]) >> 32) & 0xffffffff)
             if overflow:
-                st["pending"] = []
+                keep.extend(pending[i + 1:])  # (their slots are looked at -- and released -- by the next call)
                 raise RuntimeError(
                     "gps_gaussian_amd: a previous rasteriser call (GPSGS_CHECK=deferred) needed %d instances, more than its "
-                    "capacity; that image was not rendered. Capacity has been raised; re-run, or use GPSGS_CHECK=sync." % R)
-        else:
-            keep.append((ev, hdr, P))
-    st["pending"] = keep
+                    "capacity (or met a bin list longer than this device had seen); that image was not rendered. Capacity has been raised; re-run, "
+                    "or use GPSGS_CHECK=sync." % R)
+    finally:
+        st["pending"] = keep + st["pending"]
 
 
 def _decode(hdr):
@@ -400,7 +427,7 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
         ws_bytes = lib.gsr_workspace_bytes if needs_grad else lib.gsr_workspace_bytes_forward_only
         # a row-range view's P is only a bound: the instance capacity follows the Gaussian counts seen so far on this device
         p_est = P if rows is None else min(P, int(st.get("last_points", P) * 1.25) + 4096)
-        early = mode == "sync" and P > 0 and _early_notify
+        early = mode in ("sync", "deferred") and P > 0 and _early_notify
         ring = _ring(dev) if early else None
 
         def launch(cap):
@@ -469,6 +496,10 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
 
                     _deferred_list().append(finish)
                     break
+                if mode == "deferred":
+                    # never blocks: the notification (it lands ~40 us into this forward) is looked at by the next call on this device
+                    st["pending"].append(("note", note, cur_stream, P if rows is None else None, dev.index))
+                    break
                 if not settle(note, cap)[0]:
                     break
                 cap = _capacity_for(st, p_est)  # grown by _learn; the in-flight kernels of the failed attempt exit at once on the overflow flag
@@ -482,7 +513,7 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             _capi.check(lib.gsr_copy_header_async(_ptr(ws), hdr_ptr, stream), "gsr_copy_header_async")
             ev.record(cur_stream)
             if mode == "deferred":
-                st["pending"].append((ev, hdr, P if rows is None else None))
+                st["pending"].append(("ev", ev, hdr, P if rows is None else None))
                 break
             ev.synchronize()
             R, overflow, need = _decode(hdr)

@@ -23,7 +23,7 @@
  *       RAFTStereoHuman.upsample_flow, core/raft_stereo_human.py:69-81 (softmax over the 9 taps + unfold + weighted sum).
  *   gsr_pack_views / gsr_pack_views_backward
  *       the per-sample flatten + boolean-mask gather + concat + rgb affine of lib/GaussianRender.py:15-34.
- *   up_unproject_forward / up_unproject_backward
+ *   up_unproject_forward / up_unproject_backward (+ _dev: cameras in device memory)
  *       flow2depth + depth2pc + the validity test: lib/utils.py:113-120, :88-110, lib/network.py:66-69.
  *   fl_l1_ssim_forward / fl_l1_ssim_backward
  *       l1_loss + ssim of lib/loss.py:36-83 (and their autograd backward), called at train_stage2.py:70-72.
@@ -252,6 +252,13 @@ int up_unproject_backward(int B, int S, const float *depth, const float *mask, i
                           const float *intr_host, const float *extr_host, const float *tf_host, const float *g_depth,
                           const float *g_xyz, int64_t gx_batch_stride, int64_t gx_pixel_stride, int64_t gx_channel_stride,
                           float *d_flow, void *stream);
+/* The same with the cameras in DEVICE memory, cams_dev[B][31] = {ref_intr 3x3, intr 3x3, rows 0..2 of extr (3x4, row-major), Tf_x} per sample: nothing is
+ * read on the host (the reference keeps these tensors on the GPU, train_stage2.py:154-156; reading them back would synchronise in the middle of the network
+ * forward), one launch for any B, bit-identical results. */
+int up_unproject_forward_dev(int B, int S, const float *flow, const float *mask, int64_t mask_batch_stride, const float *cams_dev, float *depth, float *xyz,
+                             uint8_t *valid, void *stream);
+int up_unproject_backward_dev(int B, int S, const float *depth, const float *mask, int64_t mask_batch_stride, const float *cams_dev, const float *g_depth,
+                              const float *g_xyz, int64_t gx_batch_stride, int64_t gx_pixel_stride, int64_t gx_channel_stride, float *d_flow, void *stream);
 
 /* ---- 1-D correlation sampler ----------------------------------------------------------------------------------
  * volume[N,H1,W1,W2], coords[N,H1,W1] fp32 (channel 0 of the reference's [N,1,H1,W1]), out[N,2r+1,H1,W1].

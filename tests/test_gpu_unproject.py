@@ -74,3 +74,44 @@ def test_batches_larger_than_one_launch_chunk():
     for b, src in enumerate(idx):
         assert torch.equal(depth[b], d1[src]) and torch.equal(xyz[b], x1[src]) and torch.equal(valid[b], v1[src])
         assert torch.equal(flow.grad[b], flow1.grad[src])
+
+
+def test_host_camera_and_device_camera_entry_points_give_the_same_bits():
+    """The C-ABI has two forms (include/gpsgs.h): cameras as HOST arrays (by value into the kernel arguments, 16 samples per launch: what a C host
+    with its calibration in memory calls) and as a DEVICE array [B,31] (what the Python wrapper uses: no read-back, no synchronisation in the middle of
+    the network forward).  Same arithmetic, same bits, forward and backward, for a batch beyond one host-form chunk; and the device form must not
+    synchronise the host."""
+    import ctypes as C
+    import torch
+    from gps_gaussian_amd import _capi
+    from gps_gaussian_amd.unproject import unproject
+    g = np.load(os.path.join(GOLDEN, "unproject_golden.npz"))
+    dev = torch.device("cuda:0")
+    lib = _capi.lib()
+    B0 = g["flow"].shape[0]
+    idx = np.arange(19) % B0
+    B, S = len(idx), g["flow"].shape[-1]
+    flow = torch.from_numpy(g["flow"][idx]).to(dev).requires_grad_(True)
+    mask = torch.from_numpy(g["mask"][idx]).to(dev).float().contiguous()
+    cams = [torch.from_numpy(g[k][idx]).to(dev) for k in ("ref_intr", "intr", "extr", "Tf_x")]
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")        # any host synchronisation inside the wrapper raises
+    try:
+        depth, xyz, valid = unproject(flow, mask, *cams)
+        gx = torch.from_numpy(g["g_xyz"][idx]).pin_memory().to(dev, non_blocking=True)
+        (xyz * gx).sum().backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    # the host-array form, called directly
+    host = [np.ascontiguousarray(a, dtype=np.float32) for a in (g["ref_intr"][idx].reshape(B, 9), g["intr"][idx].reshape(B, 9), g["extr"][idx][:, :3, :4].reshape(B, 12),
+                                                               g["Tf_x"][idx].reshape(B))]
+    hp = [a.ctypes.data_as(C.c_void_p) for a in host]
+    d2 = torch.empty_like(depth); x2 = torch.empty_like(xyz); v2 = torch.empty((B, S * S), dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    f = flow.detach().contiguous()
+    assert lib.up_unproject_forward(B, S, p(f), p(mask), mask.stride(0), *hp, p(d2), p(x2), p(v2), st) == 0
+    gflow2 = torch.empty_like(f)
+    assert lib.up_unproject_backward(B, S, p(d2), p(mask), mask.stride(0), *hp, None, p(gx), gx.stride(0), gx.stride(1), gx.stride(2), p(gflow2), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(depth.detach(), d2) and torch.equal(xyz.detach(), x2) and torch.equal(valid, v2.bool()) and torch.equal(flow.grad, gflow2)
