@@ -670,9 +670,14 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
     hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     if (no_large_sort) return;  // the scan has turned any list longer than 1024 into an overflow (nothing downstream runs)
     // 1,025 .. 8,192 keys: 1 / 2 / 4 waves per list, keys in registers (each launch returns at once when the view's longest list is below its class)
+    // persistent grids sized to what the chip holds at once (256 CUs x 4 SIMDs x 3 / 3 / 2 waves per SIMD): a second, partial generation of
+    // workgroups would run latency-bound on an under-occupied chip while the first generation's SIMDs idle.  GPSGS_DEBUG_SORT_GRID=<n> overrides the
+    // one-wave class (development: occupancy experiments).
+    static int g1 = -1;
+    if (g1 < 0) { const char *e = getenv("GPSGS_DEBUG_SORT_GRID"); g1 = e ? atoi(e) : 3072; if (g1 <= 0) g1 = 3072; }
     const int busy_max = NB;
-    hipLaunchKernelGGL(k_sort_multi<4>, dim3(busy_max < 1024 ? busy_max : 1024), dim3(256), 0, s, bin_offset, wg_order, keys, point_list, hdr);
-    hipLaunchKernelGGL(k_sort_multi<2>, dim3(busy_max < 2048 ? busy_max : 2048), dim3(128), 0, s, bin_offset, wg_order, keys, point_list, hdr);
-    hipLaunchKernelGGL(k_sort_multi<1>, dim3(busy_max < 4096 ? busy_max : 4096), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_multi<4>, dim3(busy_max < 512 ? busy_max : 512), dim3(256), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_multi<2>, dim3(busy_max < 1536 ? busy_max : 1536), dim3(128), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_multi<1>, dim3(busy_max < g1 ? busy_max : g1), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 1024 ? NB : 1024), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

@@ -296,7 +296,53 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
     }
     const int area = bw * bh;
     if (tab && tid < 4) tab[tid] = area > GSR_BLOCK_TAB ? 0xffffffffu : (uint32_t)(tid == 0 ? bx0 : tid == 1 ? by0 : tid == 2 ? bw : bh);
-    if (area > GSR_BLOCK_TAB) {  // incoherent input: plain per-instance atomics (uniform branch)
+    if (area > GSR_BLOCK_TAB && bw <= GSR_BLOCK_TAB) {
+        // The workgroup's bins do not fit the table (uniform branch).  Normal case of this branch: the ONE workgroup whose 1024 Gaussians straddle
+        // the end of the first source view and the start of the second (pixels from the bottom and from the top of the image: a box as tall as the
+        // subject).  The table is then applied to BANDS of bin rows, one after the other.  (Until round 4 such a workgroup fell back to one GLOBAL
+        // atomic per instance: invisible with ~5 instances per Gaussian, but with scales at their clamp it is 70 dependent global atomics per thread
+        // in one workgroup -- ~100 us during which the rest of the chip had long finished: k_preprocess 142 us and k_scatter 183 us at R = 3e7,
+        // of which the per-cell work was 10 us, measured with the GSR_ABL_COUNT_* probes.)
+        const int band_h = GSR_BLOCK_TAB / bw;  // >= 1 bin rows per pass
+        for (int yb = by0; yb < by0 + bh; yb += band_h) {
+            const int yb1 = min(yb + band_h, by0 + bh), barea = (yb1 - yb) * bw;
+            const int ya = max(y0, yb), yz = min(y1, yb1);
+            __syncthreads();  // the previous band's table is done with
+            for (int t = tid; t < barea; t += GSR_BIN_THREADS) s_cnt[t] = 0u;
+            __syncthreads();
+            if (has)
+                for (int y = ya; y < yz; y++) {
+                    int xa = x0, xb = x1;
+                    hit.span(y, xa, xb);
+                    for (int x = xa; x < xb; x++)
+                        if (hit(x, y)) atomicAdd(&s_cnt[(y - yb) * bw + (x - bx0)], 1u);
+                }
+            __syncthreads();
+            for (int t = tid; t < barea; t += GSR_BIN_THREADS) {
+                const uint32_t c = s_cnt[t];
+                if (c) {
+                    const int ty = t / bw, tx = t - ty * bw;
+                    const uint32_t base = reserve((yb + ty) * bx + bx0 + tx, c);
+                    if (EMIT) { s_base[t] = base; s_cnt[t] = 0u; }
+                }
+            }
+            if (EMIT) {
+                __syncthreads();
+                if (has)
+                    for (int y = ya; y < yz; y++) {
+                        int xa = x0, xb = x1;
+                        hit.span(y, xa, xb);
+                        for (int x = xa; x < xb; x++) {
+                            if (!hit(x, y)) continue;
+                            const int t = (y - yb) * bw + (x - bx0);
+                            emit(s_base[t] + atomicAdd(&s_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
+                        }
+                    }
+            }
+        }
+        return;
+    }
+    if (area > GSR_BLOCK_TAB) {  // a box wider than the whole table (images beyond 16,384 pixels across): plain per-instance atomics (uniform branch)
         if (has)
             for (int y = y0; y < y1; y++) {
                 int xa = x0, xb = x1;
@@ -315,29 +361,18 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
         for (int y = y0; y < y1; y++) {
             int xa = x0, xb = x1;
             hit.span(y, xa, xb);
-#if defined(GSR_ABL_COUNT_NO_LOOP)  // build-time probes (never defined in a product build): what bounds the count pass with ~100-cell rects?
-            (void)xa; (void)xb;
-#elif defined(GSR_ABL_COUNT_NO_LDS_ATOMIC)
-            for (int x = xa; x < xb; x++)
-                if (hit(x, y)) s_cnt[(y - by0) * bw + (x - bx0)] = 1u;
-#else
             for (int x = xa; x < xb; x++)
                 if (hit(x, y)) atomicAdd(&s_cnt[(y - by0) * bw + (x - bx0)], 1u);
-#endif
         }
     __syncthreads();
     for (int t = tid; t < area; t += GSR_BIN_THREADS) {
         const uint32_t c = s_cnt[t];
         if (tab) tab[4 + t] = c;
-#if defined(GSR_ABL_COUNT_NO_LOOP) || defined(GSR_ABL_COUNT_NO_LDS_ATOMIC) || defined(GSR_ABL_COUNT_NO_GLOBAL_ATOMIC)
-        (void)c;  // probes: no bin ever receives a count, so R = 0 and every later kernel is a no-op (a count / scatter mismatch would corrupt the lists)
-#else
         if (c) {
             const int ty = t / bw, tx = t - ty * bw;
             const uint32_t base = reserve((by0 + ty) * bx + bx0 + tx, c);
             if (EMIT) { s_base[t] = base; s_cnt[t] = 0u; }
         }
-#endif
     }
     if (!EMIT) return;
     __syncthreads();
