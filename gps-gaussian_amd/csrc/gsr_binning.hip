@@ -379,6 +379,20 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
 // key, equal to itself, never NaN.
 constexpr uint64_t SORT_PAD = 0x7FF0000000000000ull;
 __device__ __forceinline__ bool key_lt(uint64_t a, uint64_t b) { return __longlong_as_double((long long)a) < __longlong_as_double((long long)b); }
+// min / max of two keys as ONE instruction each (v_min_f64 / v_max_f64: bit-exact on positive finite doubles and +infinity).  A compare-exchange
+// of two keys held by the same lane is then 2 instructions instead of a compare + a hazard wait + 4 selects through VCC -- the sort kernels are
+// instruction-issue bound (round 4 counters: 1.78e8 VALU instructions per k_sort_multi launch, the vector ALUs busy 2/3 of the kernel).  Inline
+// asm because fmin() / fmax() come with a canonicalising v_max_f64 x, x, x per operand (IEEE mode quiets signalling NaNs; there are none here).
+__device__ __forceinline__ uint64_t key_min(uint64_t a, uint64_t b) {
+    double r;
+    asm volatile("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+    return (uint64_t)__double_as_longlong(r);
+}
+__device__ __forceinline__ uint64_t key_max(uint64_t a, uint64_t b) {
+    double r;
+    asm volatile("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+    return (uint64_t)__double_as_longlong(r);
+}
 
 // one stage of the ascending-only bitonic network (KB = block level, ST = stage inside it; everything a compile-time constant)
 template <int KPL, int KB, int ST>
@@ -394,9 +408,8 @@ __device__ __forceinline__ void sort_stage(uint64_t (&key)[KPL], int lane) {
             const int r2 = r ^ (int)rmask;
             if (r2 > r) {
                 const uint64_t a = key[r], b = key[r2];
-                const bool sw = key_lt(b, a);
-                key[r] = sw ? b : a;
-                key[r2] = sw ? a : b;
+                key[r] = key_min(a, b);
+                key[r2] = key_max(a, b);
             }
         }
     } else {  // partner element lives in lane ^ lmask, register r ^ rmask
@@ -412,11 +425,10 @@ __device__ __forceinline__ void sort_stage(uint64_t (&key)[KPL], int lane) {
 #pragma unroll
         for (int r = 0; r < KPL; r++) {
             const uint64_t a = key[r], b = other[r];
-            // lower element of the pair keeps the minimum, upper the maximum.  Keys are unique (equal only among the +inf
-            // padding), so "b > a" is "not (b < a)": ONE 64-bit compare whose lane mask is flipped (scalar xor) for the
-            // upper lanes -- the select-between-two-compares form compiled to 9 VALU instructions per element
-            const bool take = key_lt(b, a) != !lower;
-            key[r] = take ? b : a;
+            // lower element of the pair keeps the minimum, upper the maximum: both are computed (one instruction each) and the lane's role -- a
+            // loop-invariant mask in SGPRs -- selects; no compare, so nothing is serialised through VCC
+            const uint64_t mn = key_min(a, b), mx = key_max(a, b);
+            key[r] = lower ? mn : mx;
         }
     }
 }
@@ -489,9 +501,8 @@ __device__ __forceinline__ void sm_inreg(uint64_t (&key)[SM_KPL]) {
         const int r2 = r ^ RM;
         if (r2 > r) {
             const uint64_t a = key[r], b = key[r2];
-            const bool sw = key_lt(b, a);
-            key[r] = sw ? b : a;
-            key[r2] = sw ? a : b;
+            key[r] = key_min(a, b);
+            key[r2] = key_max(a, b);
         }
     }
 }
@@ -505,10 +516,12 @@ __device__ __forceinline__ void sm_cross(uint64_t (&key)[SM_KPL], bool lower) {
         if (r2 < r) continue;
         const uint64_t mine = key[r], mine2 = key[r2];
         const uint64_t got = lane_xor64<LM>(mine2);           // the partner lane's register r2 pairs with my register r
-        key[r] = (key_lt(got, mine) != !lower) ? got : mine;  // keys are unique: one compare, flipped for the upper lane (see sort_stage)
+        const uint64_t mn = key_min(mine, got), mx = key_max(mine, got);  // both, unconditionally; the lane's role (a loop-invariant SGPR mask) selects
+        key[r] = lower ? mn : mx;
         if (r2 != r) {
             const uint64_t got2 = lane_xor64<LM>(mine);
-            key[r2] = (key_lt(got2, mine2) != !lower) ? got2 : mine2;
+            const uint64_t mn2 = key_min(mine2, got2), mx2 = key_max(mine2, got2);
+            key[r2] = lower ? mn2 : mx2;
         }
     }
 }
@@ -563,13 +576,15 @@ __device__ __forceinline__ void sm_lds_stage(uint64_t (&key)[SM_KPL], uint64_t *
 #pragma unroll
         for (int r = 0; r < SM_KPL; r++) {
             const uint64_t got = xch[r * T + tp], mine = key[r];
-            key[r] = (key_lt(got, mine) != !lower) ? got : mine;
+            const uint64_t mn = key_min(mine, got), mx = key_max(mine, got);
+            key[r] = lower ? mn : mx;
         }
     } else {  // flip: rm == 31
 #pragma unroll
         for (int r = 0; r < SM_KPL; r++) {
             const uint64_t got = xch[(r ^ (SM_KPL - 1)) * T + tp], mine = key[r];
-            key[r] = (key_lt(got, mine) != !lower) ? got : mine;
+            const uint64_t mn = key_min(mine, got), mx = key_max(mine, got);
+            key[r] = lower ? mn : mx;
         }
     }
 }
@@ -670,11 +685,12 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
     hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     if (no_large_sort) return;  // the scan has turned any list longer than 1024 into an overflow (nothing downstream runs)
     // 1,025 .. 8,192 keys: 1 / 2 / 4 waves per list, keys in registers (each launch returns at once when the view's longest list is below its class)
-    // persistent grids sized to what the chip holds at once (256 CUs x 4 SIMDs x 3 / 3 / 2 waves per SIMD): a second, partial generation of
-    // workgroups would run latency-bound on an under-occupied chip while the first generation's SIMDs idle.  GPSGS_DEBUG_SORT_GRID=<n> overrides the
-    // one-wave class (development: occupancy experiments).
+    // Grid of the one-wave class: MANY more workgroups than the chip holds at once, so that the hardware dispatcher deals the lists out dynamically
+    // (measured at R = 3e7, ~15,000 lists of ~1,700 keys: 1,091 / 651 / 571 / 470 us for 1,024 / 2,048 / 4,096 / 6,144 workgroups striding over the busy
+    // bins -- a workgroup that drew five long lists is what the others wait for).  A workgroup without a list in its class costs a few scalar loads.
+    // GPSGS_DEBUG_SORT_GRID=<n> overrides it (development).
     static int g1 = -1;
-    if (g1 < 0) { const char *e = getenv("GPSGS_DEBUG_SORT_GRID"); g1 = e ? atoi(e) : 3072; if (g1 <= 0) g1 = 3072; }
+    if (g1 < 0) { const char *e = getenv("GPSGS_DEBUG_SORT_GRID"); g1 = e ? atoi(e) : 16384; if (g1 <= 0) g1 = 16384; }
     const int busy_max = NB;
     hipLaunchKernelGGL(k_sort_multi<4>, dim3(busy_max < 512 ? busy_max : 512), dim3(256), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_multi<2>, dim3(busy_max < 1536 ? busy_max : 1536), dim3(128), 0, s, bin_offset, wg_order, keys, point_list, hdr);

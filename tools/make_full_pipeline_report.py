@@ -1,6 +1,12 @@
 #!/usr/bin/env python
-"""gpurun_out/r03/{config3,config4,config4_script}.json (tools/run_reference.py on an MI355X) -> profiles/full_pipeline.json (replayed by
-bench.py as `full_pipeline`) and profiles/r03_full_pipeline.md.   python tools/make_full_pipeline_report.py [dir] [tag]"""
+"""Round 4: the full-pipeline measurements (BASELINE configs 3 / 4: the reference's own scripts and networks on the drop-in, as the reference runs them and
+with the GPSGS_ACCELERATE import hook) -> profiles/full_pipeline.json (what bench.py replays next to its own measured leg, labelled) and
+profiles/<tag>_full_pipeline.md.
+
+    python tools/make_full_pipeline_report.py [gpurun_out/r04] [r04] [bench json with a measured full_pipeline leg]
+
+Inputs in the directory (written by tools/gpu_runs/gpu_r04_a.sh through tools/run_reference.py): config4_{plain,accel}_{default,fast}.json.
+"""
 import json
 import os
 import sys
@@ -16,54 +22,62 @@ def load(d, name):
     return json.loads(lines[-1]) if lines else None
 
 
-def main(d, tag):
-    c3, c4, c4s = load(d, "config3.json"), load(d, "config4.json"), load(d, "config4_script.json")
-    out = {"measured_on": "one MI355X (gpurun), random-init network weights, synthetic THuman-like data set on disk (tools/make_synthetic_dataset.py)",
-           "command_config3": "python tools/run_reference.py interp --res 1024 --samples 3 --views 5",
-           "command_config4": "python tools/run_reference.py ddp --res 1024 --steps 24 --batch 4 --train-samples 4"}
-    md = ["# BASELINE configs 3 and 4: the reference's OWN scripts, unmodified, on the HIP drop-in (one MI355X)", "",
-          "The reference (`test_view_interp.py`, `train_stage2.py`, its networks, data-set class, losses) is the bytecode build `oracle/stage_ref.py` leaves in the",
-          "git-ignored `oracle/_ref/GPS-Gaussian`; `tools/run_reference.py` executes the scripts as `__main__` / drives `tools/launch_stage2.py` with",
-          "`gps-gaussian_amd/dropin` ahead on `sys.path`.  Network weights are RANDOM (no checkpoint offline), the data set is synthetic, in the loader's",
-          "on-disk layout.  Random weights make the regressed scales sit at their clamp (0.01 m): splats of ~25-40 px radius at 2048^2, ~30 M",
-          "(Gaussian, bin) instances per view -- 8x the instance count of BASELINE config 2 rendered at 2048^2 (3.8 M) -- so the raster share below is an",
-          "upper bound of what trained weights produce.  The networks run in PyTorch-ROCm (MIOpen), as the north star prescribes.", ""]
-    if c3:
-        g = c3["gpu_ms_per_view"]
-        out["config3"] = {"workload": "test_view_interp.py loop: 1024^2 stereo pair -> %s render, novel_view_nums = %d, P = %d (mean)" % (c3["render"], c3["views_per_sample"], c3["gaussians_per_view"]["mean"]),
-                          "views_per_s_end_to_end_script": c3["script_run"]["views_per_s_end_to_end"], "views_per_s_within_sample": c3["script_run"].get("views_per_s_within_sample"),
-                          "views_per_s_gpu_side": c3["views_per_s_gpu_side"], "gpu_ms_per_view": g, "raster_share_of_gpu_time": c3["raster_share_of_gpu_time"]}
-        md += ["## Config 3 -- `test_view_interp.py` (16-camera-style scene directory, `novel_view_nums=5`, render %s)" % c3["render"], "",
-               "| | |", "|---|---|",
-               "| script as `__main__`, whole run (%d views: model construction, checkpoint load, loader + host rectification per sample, network + render + `.cpu()` per view) | **%.2f views/s** |" % (c3["script_run"]["views"], c3["script_run"]["views_per_s_end_to_end"]),
-               "| views of one sample following each other (no loader in between) | **%.2f views/s** |" % (c3["script_run"].get("views_per_s_within_sample") or 0),
-               "| GPU side only: network + `pts2render` (hipEvents around the reference's own calls) | %.2f views/s |" % c3["views_per_s_gpu_side"],
-               "| network forward (`RtStereoHumanModel`, RAFT-Stereo 3 iterations + regressor, AMP, PyTorch-ROCm) | %.2f ms |" % g["network"],
-               "| `pts2render` (the reference's mask gathers + `render()` -> HIP rasteriser forward) | %.2f ms, of which `render()` %.2f ms |" % (g["pts2render"], g["render"]),
-               "| Gaussians per view | %d .. %d |" % (c3["gaussians_per_view"]["min"], c3["gaussians_per_view"]["max"]),
-               "| raster share of the GPU time | %.1f %% |" % (100 * c3["raster_share_of_gpu_time"]), ""]
-    if c4:
-        g = c4["gpu_ms_per_iter"]
-        tot = sum(g.values())
-        out["config4"] = {"workload": "train_stage2.Trainer through tools/launch_stage2.py, world %d, batch %d pairs per GPU, 1024^2 -> %s" % (c4["world_size"], c4["batch_per_gpu"], c4["render"]),
-                          "iters_per_s": c4["iters_per_s"], "iter_ms": c4["iter_ms_median_second_half"], "gpu_ms_per_iter": g, "exchange": c4["exchange"], "backend": c4["backend"]}
-        md += ["## Config 4 -- `train_stage2.Trainer` via `tools/launch_stage2.py`, world size %d, batch %d stereo pairs per GPU, render %s" % (c4["world_size"], c4["batch_per_gpu"], c4["render"]), "",
-               "| | |", "|---|---|",
-               "| **stage-2 iterations/s** (median of the second half of %d iterations; host time between optimizer steps, DataLoader + the reference's `.item()` syncs included) | **%.3f it/s** (%.1f ms) |" % (c4["steps"], c4["iters_per_s"], c4["iter_ms_median_second_half"]),
-               "| network forward (AMP) | %.1f ms |" % g["network_forward"],
-               "| `pts2render` (reference's own: per-sample mask gathers + 4 x HIP raster forward) | %.2f ms |" % g["pts2render"],
-               "| `l1_loss` + `ssim` (reference's `lib/loss.py`, eager PyTorch at [4,3,2048,2048]) | %.2f + %.2f ms |" % (g["loss_l1"], g["loss_ssim"]),
-               "| `scaler.scale(loss).backward()` (networks + loss + 4 x HIP raster backward) | %.1f ms |" % g["backward"],
-               "| `scaler.step(optimizer)` | %.2f ms |" % g["optimizer_step"],
-               "| sum of the spans | %.1f ms |" % tot,
-               "| exchange step | %s (%s) |" % (c4["exchange"], c4["backend"] or "one rank: not issued"), ""]
-    if c4s:
-        out["config4_script"] = c4s
-        md += ["`train_stage2.py` as `__main__` (one process, same sizes, batch %d): %s optimizer steps of %d iterations (the GradScaler skips steps while it calibrates its scale), "
-               "%.3f it/s over the second half, final checkpoint written, weights finite: %s." % (c4s["batch"], c4s["optimizer_steps"], c4s.get("total_steps", 0), c4s.get("iters_per_s_second_half") or 0, c4s.get("finite_weights")), ""]
-    md += ["The north star's raster-only targets (>= 25 views/s at 1024^2, 600 k Gaussians) are met by two orders of magnitude in `bench.py` (`value`); the full pipeline is",
-           "bounded by the PyTorch-ROCm networks and, in training, by the reference's eager SSIM (the fused L1 + SSIM of `gps_gaussian_amd.loss` takes 0.5 ms for the",
-           "same tensors: a one-line swap a maintainer can make, INTEGRATION.md).", ""]
+def c4_row(label, c):
+    g = c["gpu_ms_per_iter"]
+    return "| %s | **%.3f** | %.1f | %.1f | %.2f | %.2f + %.2f | %.1f | %.2f |" % (label, c["iters_per_s"], c["iter_ms_median_second_half"], g["network_forward"], g["pts2render"],
+                                                                                 g["loss_l1"], g["loss_ssim"], g["backward"], g["optimizer_step"])
+
+
+def main(d, tag, bench_json):
+    pd, ad, pf, af = (load(d, "config4_%s.json" % n) for n in ("plain_default", "accel_default", "plain_fast", "accel_fast"))
+    fp = None
+    if bench_json and os.path.exists(bench_json):
+        lines = [l for l in open(bench_json) if l.startswith("{")]
+        fp = json.loads(lines[-1]).get("full_pipeline") if lines else None
+    out = {"measured_on": "one MI355X (gpurun), random-init network weights, synthetic THuman-like data set on disk (tools/make_synthetic_dataset.py), round 4",
+           "command_config4": "python tools/run_reference.py ddp --res 1024 --steps 16 --batch 4 --train-samples 4 [--accelerate all]   (MIOpen default find mode)"}
+    md = ["# BASELINE configs 3 and 4: the reference's OWN scripts, unmodified, on the HIP drop-in (one MI355X) -- as the reference runs them, and with the import hook", "",
+          "The reference (`test_view_interp.py`, `train_stage2.py`, its networks, data-set class, losses) is the bytecode build `oracle/stage_ref.py` leaves in the git-ignored",
+          "`oracle/_ref/GPS-Gaussian`; `tools/run_reference.py` executes the scripts as `__main__` / drives `tools/launch_stage2.py` with `gps-gaussian_amd/dropin` ahead on",
+          "`sys.path`.  Weights are RANDOM (no checkpoint offline) and the data set is synthetic: the regressed scales sit at their 0.01 m clamp, ~3e7 (Gaussian, bin) instances per",
+          "2048^2 view.  **as the reference runs it** = only the two external extensions are replaced (rows a1-a14).  **GPSGS_ACCELERATE=all** = the opt-in import hook",
+          "(`gps-gaussian_amd/accelerate.py`) additionally rebinds the reference's `pts2render`, `l1_loss` / `ssim`, `CorrBlockFast1D`, `upsample_flow`, `flow2depth` / `depth2pc` to the",
+          "fused kernels of SURVEY section 8(f) as its modules load -- no reference file is touched, the scripts are the same bytes.", ""]
+    if pd and ad:
+        out["config4"] = {"workload": "train_stage2.Trainer through tools/launch_stage2.py, world 1, batch %d pairs per GPU, 1024^2 -> %s" % (pd["batch_per_gpu"], pd["render"]),
+                          "iters_per_s": pd["iters_per_s"], "iter_ms": pd["iter_ms_median_second_half"], "gpu_ms_per_iter": pd["gpu_ms_per_iter"], "exchange": pd["exchange"], "backend": pd["backend"]}
+        out["config4_accelerated"] = {"workload": out["config4"]["workload"] + ", GPSGS_ACCELERATE=all", "iters_per_s": ad["iters_per_s"], "iter_ms": ad["iter_ms_median_second_half"],
+                                      "gpu_ms_per_iter": ad["gpu_ms_per_iter"], "fused_calls": ad["accelerate"]["calls"], "rebound": ad["accelerate"]["rebound"]}
+        md += ["## Config 4 -- `train_stage2.Trainer` via `tools/launch_stage2.py`, world size 1, batch 4 stereo pairs per GPU, render 2048x2048", "",
+               "(stage-2 iterations/s = median of the second half of 16 iterations, host time between optimizer steps, DataLoader and the reference's `.item()` syncs included; the other",
+               "columns are hipEvent spans around the reference's own calls, ms per iteration)", "",
+               "| | **it/s** | iteration ms | network forward | `pts2render` | `l1_loss` + `ssim` | `backward()` | optimizer |", "|---|---|---|---|---|---|---|---|",
+               c4_row("as the reference runs it, MIOpen default find mode (5 min 24 s of search on a fresh box)", pd), c4_row("GPSGS_ACCELERATE=all, default find mode", ad)]
+        if pf and af:
+            md += [c4_row("as the reference runs it, MIOPEN_FIND_MODE=FAST (58 s wall including the data set)", pf), c4_row("GPSGS_ACCELERATE=all, MIOPEN_FIND_MODE=FAST", af)]
+        md += ["", "The hook takes the iteration from %.1f to %.1f ms (**%.2f -> %.2f it/s, x%.2f**): the reference's eager SSIM forward (%.1f ms) and its share of the backward become the fused"
+               % (pd["iter_ms_median_second_half"], ad["iter_ms_median_second_half"], pd["iters_per_s"], ad["iters_per_s"], ad["iters_per_s"] / pd["iters_per_s"], pd["gpu_ms_per_iter"]["loss_ssim"]),
+               "kernel pair (%.2f ms), the ten boolean-mask gathers + syncs per sample of `pts2render` become the fused pack + one autograd node for the batch (%.1f -> %.1f ms), the backward"
+               % (ad["gpu_ms_per_iter"]["loss_l1"] + ad["gpu_ms_per_iter"]["loss_ssim"], pd["gpu_ms_per_iter"]["pts2render"], ad["gpu_ms_per_iter"]["pts2render"]),
+               "span drops from %.1f to %.1f ms.  What is left is the PyTorch-ROCm networks (forward %.0f ms, most of the backward): `profiles/%s_config4_kernel_stats.md` splits one iteration's"
+               % (pd["gpu_ms_per_iter"]["backward"], ad["gpu_ms_per_iter"]["backward"], ad["gpu_ms_per_iter"]["network_forward"], tag),
+               "kernel time by family.  Fused calls in the 16 iterations: %s." % json.dumps(ad["accelerate"]["calls"]), ""]
+    if fp and fp.get("measured_in_this_run"):
+        md += ["## Measured inside `bench.py` (the `full_pipeline` leg: what the driver's bench run observes; MIOPEN_FIND_MODE=%s, %s s for the four child runs)" % (fp.get("miopen_find_mode"), fp.get("leg_wall_s")), "",
+               "| leg | result |", "|---|---|"]
+        for k in ("config4_stage2_accelerated", "config4_stage2_as_the_reference_runs_it", "config3_view_interp_accelerated", "config3_view_interp_as_the_reference_runs_it"):
+            v = fp.get(k) or {}
+            if not v.get("measured_in_this_run"):
+                md.append("| %s | %s |" % (k, v.get("skipped") or v.get("error") or "not run"))
+            elif "stage2_iters_per_s" in v:
+                md.append("| %s | **%.3f it/s** (%.1f ms): %s |" % (k, v["stage2_iters_per_s"], v["iter_ms"], ", ".join("%s %.1f" % kv for kv in v["gpu_ms_per_iter"].items())))
+            else:
+                md.append("| %s | %.2f views/s inside a sample, %.2f over the whole script, %.2f GPU side: %s |" % (k, v.get("views_per_s_within_sample") or 0, v["views_per_s_whole_script"],
+                                                                                                                 v.get("views_per_s_gpu_side") or 0, ", ".join("%s %.2f ms" % kv for kv in (v.get("gpu_ms_per_view") or {}).items())))
+        md.append("")
+        out["bench_leg_example"] = {k: fp[k] for k in fp if k != "replayed_default_find_mode"}
+    md += ["The north star's raster-only targets (>= 25 views/s at 1024^2, 600 k Gaussians) are met by two orders of magnitude in `bench.py` (`value`); the full pipeline is bounded by the",
+           "PyTorch-ROCm networks, which the north star leaves in PyTorch (55 % of config 3's kernel time is ATen's GroupNorm moments kernel, `profiles/r03_config3_kernel_stats.md`).", ""]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", "full_pipeline.json"), "w"), indent=1)
     open(os.path.join(ROOT, "profiles", "%s_full_pipeline.md" % tag), "w").write("\n".join(md))
@@ -71,4 +85,4 @@ def main(d, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03"), sys.argv[2] if len(sys.argv) > 2 else "r03")
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04"), sys.argv[2] if len(sys.argv) > 2 else "r04", sys.argv[3] if len(sys.argv) > 3 else None)
