@@ -342,3 +342,36 @@ def test_train_stage2_reaches_the_fused_kernels_through_the_import_hook(tmp_path
         assert worst[k] <= max(2e-3, 3 * noise[k]), (k, worst, noise)
     assert plain["optimizer_steps"] == fused["optimizer_steps"] and rel_w <= max(2e-3, 3 * noise_w), (rel_w, noise_w, plain["optimizer_steps"], fused["optimizer_steps"])
     assert abs(plain["evals"][0]["val_psnr"] - fused["evals"][0]["val_psnr"]) < 0.05
+
+
+def test_full_size_view_regressed_by_the_real_networks_matches_the_oracle(tmp_path):
+    """BASELINE config 3 at FULL size: the reference's test_view_interp.py as __main__ on a 1024^2 stereo pair -> one 2048^2 novel view, its
+    real networks (random weights: every scale at the 0.01 m clamp, ~3e7 (Gaussian, bin) instances).  The Gaussians the reference's own pts2render handed to
+    the rasteriser for that view are dumped (GPSGS_DUMP_INPUTS) and the view is rendered again here by the HIP rasteriser and by the CPU oracle: radii equal,
+    RGB within 1e-4 away from branch thresholds -- the parity statement on the data the real caller produces, not on a synthetic cloud."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import hip_render, oracle_render
+    dump = str(tmp_path / "last_view.npz")
+    res = _tool([os.path.join(ROOT, "tools", "run_reference.py"), "interp", "--res", "1024", "--samples", "1", "--views", "1", "--work", str(tmp_path / "w")],
+                env={"GPSGS_DUMP_INPUTS": dump, "MIOPEN_FIND_MODE": os.environ.get("MIOPEN_FIND_MODE", "FAST")}, timeout=1500)
+    assert res["script_run"]["views"] == 1 and res["render"] == "2048x2048"
+    d = np.load(dump)
+    P = d["means3D"].shape[0]
+    assert P > 300000 and int(d["W"]) == 2048 and int(d["H"]) == 2048
+    scene = dict(means3D=d["means3D"], colors=d["colors"], opacities=d["opacities"].reshape(-1, 1), scales=d["scales"], rotations=d["rotations"],
+                 view=d["view"].reshape(4, 4), proj=d["proj"].reshape(4, 4), campos=np.zeros(3, np.float32), W=2048, H=2048, tanfovx=float(d["tanfovx"]),
+                 tanfovy=float(d["tanfovy"]), bg=d["bg"].astype(np.float32), scale_modifier=float(d["scale_modifier"]))
+    assert float(np.median(scene["scales"])) > 0.009          # the heads really sit at their clamp
+    img, radii, _, _ = hip_render(scene, debug=True)          # debug: the forward validates its bin lists (ids, order, cursors)
+    o, oimg, oradii = oracle_render(scene, "f32")
+    np.testing.assert_array_equal(radii, oradii)
+    assert o.num_rendered > 5e6
+    solid = o.fragility() > 1e-5
+    err = np.abs(img - oimg).max(0)
+    print({"P": P, "tile_instances": int(o.num_rendered), "median_radius_px": float(np.median(oradii[oradii > 0])), "rgb_max_err_solid": float(err[solid].max()),
+           "solid_fraction": float(solid.mean()), "pixels_over_tol": int((err[solid] > 1e-4).sum())})
+    # lists are thousands of splats deep: T carries ~1e-4 of accumulated rounding where it meets the 1e-4 stop threshold (see test_gpu_raster.py::
+    # test_large_splats_tens_of_millions_of_instances): a handful of pixels outside the 1e-5 band may stop one splat earlier or later than the oracle
+    assert solid.mean() > 0.97 and (err[solid] > 1e-4).sum() <= 1e-5 * err.size, ((err[solid] > 1e-4).sum(), float(err[solid].max()))
+    assert err.max() <= 2.0 / 255 + 1e-3
