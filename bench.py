@@ -304,7 +304,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary `configs` block (config 2 rendered at 2048^2, config 5)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip every secondary leg (autograd module, forward only, deferred check, stage-2 path, HIP graph, CPU rows): with --inflight 1 "
-                         "every kernel launch of the run then has the chip to itself (tools/prof_r02.sh profiles that mode for the exclusive durations)")
+                         "every kernel launch of the run then has the chip to itself (tools/prof_r04.sh profiles that mode for the exclusive durations)")
     ap.add_argument("--graph-leg", action="store_true", help="(internal) time HIP-graph replays of the fwd+bwd step and print one JSON line")
     ap.add_argument("--no-full-pipeline", action="store_true", help="skip the `full_pipeline` leg (BASELINE configs 3 / 4 with the reference's own scripts and networks)")
     ap.add_argument("--full-pipeline-budget", type=float, default=600.0, help="seconds the full-pipeline leg may take in total; what does not fit is skipped and says so")
@@ -636,7 +636,7 @@ def main():
     if dom:
         achieved = per_stage[dom]["hbm_gbs"]
         traffic, valu_instr, pmc_src = None, None, None
-        # HBM traffic / VALU instruction counts come from separate rocprofv3 --pmc passes (tools/prof.sh writes profiles/pmc_traffic.json
+        # HBM traffic / VALU instruction counts come from separate rocprofv3 --pmc passes (tools/prof_r04.sh writes profiles/pmc_traffic.json
         # with the workload it was measured on); they are reported ONLY when this run is that workload, otherwise null
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):

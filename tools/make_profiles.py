@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 output of tools/prof_r03.sh (prof_r02.sh) into the tracked evidence files:
+"""Turn the rocprofv3 output of tools/prof_r04.sh into the tracked evidence files:
    gpurun_out/prof_<tag>/{kernel_stats.md, pmc_summary.md, pmc_traffic.json}   (copy them to profiles/ to commit)
 Usage: python tools/make_profiles.py <prof dir> <tag>"""
 import collections, csv, glob, json, os, sys
