@@ -692,8 +692,10 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
     static int g1 = -1;
     if (g1 < 0) { const char *e = getenv("GPSGS_DEBUG_SORT_GRID"); g1 = e ? atoi(e) : 16384; if (g1 <= 0) g1 = 16384; }
     const int busy_max = NB;
-    hipLaunchKernelGGL(k_sort_multi<4>, dim3(busy_max < 512 ? busy_max : 512), dim3(256), 0, s, bin_offset, wg_order, keys, point_list, hdr);
-    hipLaunchKernelGGL(k_sort_multi<2>, dim3(busy_max < 1536 ? busy_max : 1536), dim3(128), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    // (the same holds for the two- and four-wave classes: with the real networks' Gaussians -- lists up to ~3,000 keys -- the two-wave class is the
+    //  largest: 409 us on 1,536 workgroups, profiles/r04_config3_kernel_stats.md)
+    hipLaunchKernelGGL(k_sort_multi<4>, dim3(busy_max < 2048 ? busy_max : 2048), dim3(256), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_multi<2>, dim3(busy_max < 8192 ? busy_max : 8192), dim3(128), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_multi<1>, dim3(busy_max < g1 ? busy_max : g1), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 1024 ? NB : 1024), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }

@@ -347,15 +347,15 @@ def test_train_stage2_reaches_the_fused_kernels_through_the_import_hook(tmp_path
 def test_full_size_view_regressed_by_the_real_networks_matches_the_oracle(tmp_path):
     """BASELINE config 3 at FULL size: the reference's test_view_interp.py as __main__ on a 1024^2 stereo pair -> one 2048^2 novel view, its
     real networks (random weights: every scale at the 0.01 m clamp, ~3e7 (Gaussian, bin) instances).  The Gaussians the reference's own pts2render handed to
-    the rasteriser for that view are dumped (GPSGS_DUMP_INPUTS) and the view is rendered again here by the HIP rasteriser and by the CPU oracle: radii equal,
+    the rasteriser for its last view are dumped (GPSGS_DUMP_INPUTS) and the view is rendered again here by the HIP rasteriser and by the CPU oracle: radii equal,
     RGB within 1e-4 away from branch thresholds -- the parity statement on the data the real caller produces, not on a synthetic cloud."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import hip_render, oracle_render
     dump = str(tmp_path / "last_view.npz")
-    res = _tool([os.path.join(ROOT, "tools", "run_reference.py"), "interp", "--res", "1024", "--samples", "1", "--views", "1", "--work", str(tmp_path / "w")],
+    res = _tool([os.path.join(ROOT, "tools", "run_reference.py"), "interp", "--res", "1024", "--samples", "1", "--views", "2", "--work", str(tmp_path / "w")],
                 env={"GPSGS_DUMP_INPUTS": dump, "MIOPEN_FIND_MODE": os.environ.get("MIOPEN_FIND_MODE", "FAST")}, timeout=1500)
-    assert res["script_run"]["views"] == 1 and res["render"] == "2048x2048"
+    assert res["script_run"]["views"] == 2 and res["render"] == "2048x2048"
     d = np.load(dump)
     P = d["means3D"].shape[0]
     assert P > 300000 and int(d["W"]) == 2048 and int(d["H"]) == 2048
