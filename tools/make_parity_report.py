@@ -3,7 +3,7 @@ Usage: python tools/make_parity_report.py [tag]"""
 import json, os, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 rows = [json.loads(l) for l in open(os.path.join(root, "gpurun_out", "parity_report.jsonl")) if l.strip()]
 L = ["# Parity report of the GPU suite (`python -m pytest tests -m gpu`, MI355X): HIP path vs the fp32 C oracle on the same inputs.",
      "# Source: gpurun_out/parity_report.jsonl (tests/conftest.py::parity_report), formatted by tools/make_parity_report.py.",
