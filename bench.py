@@ -588,7 +588,7 @@ def main():
             torch.cuda.empty_cache()
         # the regime BASELINE configs 3 / 4 REALLY run in offline (and stage-2 training starts in): freshly initialised regression heads put every
         # scale at its 0.01 m clamp (lib/gs_parm_network.py:43,76) -- ~25 px splats at 2048^2, ~55 bins per Gaussian, R ~ 3 x 10^7, ~20,000 bins
-        # with lists of 1,000-3,000 entries (profiles/r03_full_pipeline.md).  Synthetic stand-in with the same statistics, per-kernel table included.
+        # with lists of 1,000-3,000 entries (profiles/r04_full_pipeline.md, profiles/r04_regime_kernel_stats.md).  Synthetic stand-in with the same statistics, per-kernel table included.
         try:
             configs["config3_regime_untrained_heads_2048 (scales at the 0.01 m clamp, opacity ~0.5: what random network weights give)"] = \
                 config_leg(1024, 550000, 2048, dev, 10, 2, rs, timed, attributes="untrained", stage_table=True)
@@ -663,7 +663,7 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": dom_us,
                     "launches_averaged": int(dom_excl[1]) if dom == dom_stage else None,
                     "measured": "hipEvents around the kernel on its launch stream over a timed region of %d steps with ONE view in flight (exclusive "
-                                "duration; profiles/r03_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % n_single,
+                                "duration; profiles/r04_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % n_single,
                     "bound_note": "the contract's roofline is HBM; this kernel's HBM fraction is low by construction (>= 50 op/B).  With a view on its own it is bound by the shape of the work -- 5 one-wave work items of ~370 list entries per SIMD, a lone wave is latency-bound -- not by VALU issue: adding 18 % VALU instructions per pair costs 4 % (profiles/r03_issue_probes.md, DESIGN.md section 4)",
                     # the same kernel inside the headline region: F views in flight, launches of different views overlap and time-share the chip
                     "headline_region": {"views_in_flight": F, "avg_launch_us": ovl_us,

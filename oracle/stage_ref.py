@@ -16,6 +16,12 @@ gps-gaussian_amd/ imports from it.
 
 `prepare_data/` (offline data-set rendering, taichi) and `train_stage1.py` (no rasteriser in stage 1) are outside the hot path and
 are not staged.
+
+Provenance / licence note: the reference (and the Inria rasteriser licence header it carries, gaussian_renderer/__init__.py:1-10) is released
+for non-commercial research and evaluation use only.  The staged bytecode and YAML files are DERIVED from it: they exist solely so that the
+parity tests and the full-pipeline measurement can run the reference's own code on the GPU box, they are never committed, never imported
+by the product, and must not be redistributed with it; a build from a tree without /root/reference simply has no oracle/_ref (the
+reference tests skip, bench.py's full_pipeline leg says "no reference").
 """
 import hashlib
 import json
