@@ -282,15 +282,19 @@ def test_launcher_world_1_with_the_real_networks(tmp_path):
     timing file has one hipEvent span per iteration for the reference's own calls."""
     import make_synthetic_dataset as M
     data_root = str(tmp_path / "data")
-    M.make_dataset(data_root, res=256, n_train=2, n_val=1, quiet=True)
+    M.make_dataset(data_root, res=256, n_train=2, n_val=2, quiet=True)   # two validation samples: len_val = 1 batch (train_stage2.py:38)
     work = refenv.make_workdir(REF, str(tmp_path / "w"), {"stage1_ckpt": "None", "dataset": {"src_res": 256, "data_root": data_root}})
     tfile = str(tmp_path / "timing.json")
     res = _tool([os.path.join(ROOT, "tools", "launch_stage2.py"), "--reference", REF, "--workdir", work, "--steps", "5", "--exp-root", str(tmp_path / "exp"),
-                 "--timing", tfile, "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", "1000"],
+                 "--timing", tfile, "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", "3"],   # validation INSIDE the run (after iteration 3)
                 env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29553", "GPSGS_DIST_FORCE": "1"})
     # GPSGS_DIST_FORCE=1: the process group is initialised (backend nccl = RCCL) and the exchange step -- the mean all-reduce of all 5,144,408
     # gradients hooked into GradScaler.unscale_ -- is ISSUED at world size 1: RCCL runs inside the reference's own training loop
     assert res["world_size"] == 1 and res["steps"] == 5 and res["backend"] == "nccl", res
+    # Trainer.run_eval ran through the launcher's eval-then-barrier wrapper (train_stage2.py:92-96, :103-139): it writes one preview image per pass
+    shows = [f for dp, _, fs in os.walk(str(tmp_path / "exp")) for f in fs if dp.endswith("show")]
+    assert shows == ["3.jpg"], shows
+    assert res["exchange_overlapped_with_backward"] is True
     t = json.load(open(tfile))
     for k in ("network_forward", "pts2render", "loss_l1", "loss_ssim", "backward", "optimizer_step"):
         assert len(t[k]) == 5 and min(t[k]) > 0, (k, t[k])
