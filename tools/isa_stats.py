@@ -14,6 +14,7 @@ unit = os.path.basename(path)
 flags = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 if unit in ("gsr_preprocess.hip",): flags += ["-ffp-contract=off", "-fno-slp-vectorize"]
 if unit in ("corr_sampler.hip", "pack_views.hip", "unproject.hip", "gsr_binning.hip"): flags += ["-ffp-contract=off"]
+if unit == "gsr_binning.hip": flags += ["-mllvm", "-simplifycfg-sink-common=false"]
 if unit.startswith("gsr_composite"): flags += ["-fno-slp-vectorize"]
 out = "/tmp/isa_%s.s" % unit
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *flags, *extra, "-S", "--cuda-device-only", "-o", out, path], check=True, stderr=subprocess.DEVNULL)
