@@ -262,7 +262,6 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
                                                         const uint32_t *__restrict__ goff, const uint32_t *__restrict__ gpart,
                                                         const uint8_t *__restrict__ inst_valid, const float *__restrict__ inst_dop,
                                                         const GsrGradAcc *__restrict__ inst_grad, const GsrHeader *__restrict__ hdr) {
-    __shared__ uint4 s_flags[4][256];  // one 4 KiB tile of gradient-record flags per wave (large-rect path only)
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t row0;
     int nP;
@@ -296,43 +295,25 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
             // summation order as below: bit-identical sums).  The unconditional form below moved 37 bytes for every slot: 2 GB and 1.4 ms per view
             // in BASELINE config 4 with random weights (profiles/r04_config4_kernel_stats.md), 95 % of it records nobody had written.
             // (flags are the bytes 0 / 1; they are read as ALIGNED 16-byte words covering the run -- the section is 256-byte aligned and padded, and
-            //  whatever lies outside [s0, s1) is masked off -- instead of 16 single-byte loads per step: one memory instruction per 16 slots)
-            // The lanes that come here read their flag runs TOGETHER: the runs of a wave's Gaussians are consecutive in memory (Gaussian-major
-            // slots), so the wave streams [first lane's s0, last lane's s1) through a 4 KiB LDS tile with coalesced 16-byte loads and every lane
-            // then picks its own run out of LDS.  (Per-lane reads of the same bytes -- round 4's first form -- touch a different cache line per lane
-            // and instruction: 57 % of the kernel's wave cycles were spent waiting, profiles/r04_regime_kernel_stats.md.)
-            const int lane = threadIdx.x & 63;
-            uint4 *tile = s_flags[threadIdx.x >> 6];
-            const uint64_t act = __ballot(1);  // the lanes of this wave on this path (runs ascend with the lane index)
-            const uint32_t nact = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
-            const uint32_t A = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0) & ~15u;
-            const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)s1, 63 - __builtin_clzll(act));
-            for (uint32_t c = A; c < B; c += 4096u) {  // wave-uniform
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();  // the previous tile has been consumed by every lane
-                for (uint32_t pc = rank; pc < 256u && c + 16u * pc < B; pc += nact)
-                    tile[pc] = *reinterpret_cast<const uint4 *>(inst_valid + c + 16u * pc);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t lo_b = max(s0 & ~15u, c), hi_b = min(s1, c + 4096u);
-                for (uint32_t base = lo_b; base < hi_b; base += 16u) {
-                    const uint4 f = tile[(base - c) >> 4];
-                    auto nib = [](uint32_t w) { w &= 0x01010101u; return (w | (w >> 7) | (w >> 14) | (w >> 21)) & 0xFu; };
-                    uint32_t m = nib(f.x) | (nib(f.y) << 4) | (nib(f.z) << 8) | (nib(f.w) << 12);
-                    const uint32_t lo = s0 > base ? s0 - base : 0u, hi = min(16u, s1 - base);
-                    m &= (0xFFFFu >> (16u - hi)) & ~((1u << lo) - 1u);
-                    while (m) {
-                        const int u = __builtin_ctz(m);
-                        m &= m - 1u;
-                        const uint32_t ri = base + (uint32_t)u;
-                        const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri);
-                        const float4 b0 = r[0], b1 = r[1];
-                        const float b2 = inst_dop[ri];
-                        g0.x += b0.x; g0.y += b0.y; g0.z += b0.z; g0.w += b0.w;
-                        g1.x += b1.x; g1.y += b1.y; g1.z += b1.z; g1.w += b1.w;
-                        g2x += b2;
-                    }
+            //  whatever lies outside [s0, s1) is masked off -- instead of 16 single-byte loads per step: one memory instruction per 16 slots.
+            //  Tried and reverted: streaming a wave's consecutive flag runs through a 4 KiB LDS tile with coalesced loads -- 307 us either way at
+            //  R = 3e7: ~24 % of the slots hold a record there, and what the kernel waits for is the scattered 36-byte record reads, not the flags.)
+            for (uint32_t base = s0 & ~15u; base < s1; base += 16u) {
+                const uint4 f = *reinterpret_cast<const uint4 *>(inst_valid + base);
+                auto nib = [](uint32_t w) { w &= 0x01010101u; return (w | (w >> 7) | (w >> 14) | (w >> 21)) & 0xFu; };
+                uint32_t m = nib(f.x) | (nib(f.y) << 4) | (nib(f.z) << 8) | (nib(f.w) << 12);
+                const uint32_t lo = s0 > base ? s0 - base : 0u, hi = min(16u, s1 - base);
+                m &= (0xFFFFu >> (16u - hi)) & ~((1u << lo) - 1u);
+                while (m) {
+                    const int u = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t ri = base + (uint32_t)u;
+                    const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri);
+                    const float4 b0 = r[0], b1 = r[1];
+                    const float b2 = inst_dop[ri];
+                    g0.x += b0.x; g0.y += b0.y; g0.z += b0.z; g0.w += b0.w;
+                    g1.x += b1.x; g1.y += b1.y; g1.z += b1.z; g1.w += b1.w;
+                    g2x += b2;
                 }
             }
         } else
