@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const uint32_t gbase = gpart[gb];
         const uint32_t s0 = gbase + goff[i];
         const uint32_t s1 = ((i & 1023) != 1023 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * 1024 < q.P ? gpart[gb + 1] : hdr->num_slots);
-        if (s1 - s0 > 16u) {
+        if (s1 - s0 > q.flags_first_min) {
             // LARGE rects (scales at their clamp: ~100 slots per Gaussian, of which the compositing backward wrote a handful -- the splat is hidden
             // in most of its bins): read 16 FLAGS per step, then fetch only the records that exist, in slot order (the same
             // summation order as below: bit-identical sums).  The unconditional form below moved 37 bytes for every slot: 2 GB and 1.4 ms per view
@@ -458,5 +458,9 @@ void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, co
                                const uint8_t *inst_valid, const float *inst_dop, const GsrGradAcc *inst_grad, const GsrHeader *hdr,
                                hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + 255) / 256), dim3(256), 0, s, p, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    GsrBwdParams q = p;
+    static int thr = -1;  // GPSGS_DEBUG_FLAGS_FIRST=<slots>: development knob for the threshold of the flags-first gather
+    if (thr < 0) { const char *e = getenv("GPSGS_DEBUG_FLAGS_FIRST"); thr = e ? atoi(e) : 16; if (thr < 0) thr = 16; }
+    q.flags_first_min = (uint32_t)thr;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }
