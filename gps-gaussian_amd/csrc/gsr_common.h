@@ -479,7 +479,7 @@ struct GsrBwdParams {
     const int *radii;
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dscales, *dL_drotations;
     const uint32_t *row_range;  // as in GsrFwdParams
-    uint32_t flags_first_min;   // runs of more gradient-record slots than this read their flags before their records (k_preprocess_bwd)
+    uint32_t flags_first_min;   // runs of more gradient-record slots than this read their flags before their records (k_preprocess_bwd); ~0u: chosen per view
 };
 
 #if defined(__HIPCC__)

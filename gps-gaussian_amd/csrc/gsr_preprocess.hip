@@ -289,7 +289,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const uint32_t gbase = gpart[gb];
         const uint32_t s0 = gbase + goff[i];
         const uint32_t s1 = ((i & 1023) != 1023 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * 1024 < q.P ? gpart[gb + 1] : hdr->num_slots);
-        if (s1 - s0 > q.flags_first_min) {
+        // Flags first for runs of more than `ffm` slots.  The unconditional form (4 slots per step, every load in flight) wins while the records of a
+        // view fit the 256 MB Infinity Cache and most slots hold one (config 2: 2.3 M slots x 37 B, 82 % written: 35.2 us against 37.9); beyond that the
+        // kernel is HBM-bound and every record it does not read counts (measured: config 2 rendered at 2048^2 -- what stage 2 renders -- 91.9 -> 74.4 us,
+        // config 5 313.6 -> 230.9 us with the threshold at 4 instead of 16).  The slot count is in the header: a wave-uniform choice.
+        const uint32_t ffm = q.flags_first_min != 0xffffffffu ? q.flags_first_min : (hdr->num_slots > 4000000u ? 4u : 16u);
+        if (s1 - s0 > ffm) {
             // LARGE rects (scales at their clamp: ~100 slots per Gaussian, of which the compositing backward wrote a handful -- the splat is hidden
             // in most of its bins): read 16 FLAGS per step, then fetch only the records that exist, in slot order (the same
             // summation order as below: bit-identical sums).  The unconditional form below moved 37 bytes for every slot: 2 GB and 1.4 ms per view
@@ -459,8 +464,8 @@ void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, co
                                hipStream_t s) {
     if (p.P <= 0) return;
     GsrBwdParams q = p;
-    static int thr = -1;  // GPSGS_DEBUG_FLAGS_FIRST=<slots>: development knob for the threshold of the flags-first gather
-    if (thr < 0) { const char *e = getenv("GPSGS_DEBUG_FLAGS_FIRST"); thr = e ? atoi(e) : 16; if (thr < 0) thr = 16; }
-    q.flags_first_min = (uint32_t)thr;
+    static long thr = -2;  // GPSGS_DEBUG_FLAGS_FIRST=<slots>: development knob for the threshold of the flags-first gather (unset: chosen per view)
+    if (thr == -2) { const char *e = getenv("GPSGS_DEBUG_FLAGS_FIRST"); thr = e ? atol(e) : -1; }
+    q.flags_first_min = thr < 0 ? 0xffffffffu : (uint32_t)thr;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }
