@@ -554,12 +554,14 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
     N = m3.shape[0]
     P = N if rows is None else rows.capacity
     H, W = int(rs.image_height), int(rs.image_width)
-    g = grad_out_color.detach().to(dtype=torch.float32).contiguous()  # H3: may arrive non-contiguous
+    g = grad_out_color  # H3: may arrive non-contiguous (or in another dtype); the common case -- fp32, contiguous -- is used as it is
+    if g.dtype is not torch.float32 or not g.is_contiguous() or g.requires_grad:
+        g = g.detach().to(dtype=torch.float32).contiguous()
     with _device_guard(dev):
         st = _dev_state(dev)
         if _check_mode() != "none":
             _drain_pending(st, block=(_check_mode() == "deferred"))
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)  # the raw handle: torch.cuda.current_stream() builds a Stream object (~3 us)
         if arena is not None and all(a.dtype == torch.float32 and a.is_contiguous() and a.device == dev and tuple(a.shape) == (N, c)
                                      for a, c in zip(arena[:5], (3, 3, 1, 3, 4))):
             d_m3, d_col, d_op, d_sc, d_rot = arena[:5]
@@ -568,13 +570,12 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
             raise RuntimeError("gps_gaussian_amd: a row-range view needs its batch-wide gradient arrays")
         else:
             # one allocation, six contiguous gradient arrays carved out of it (quaternion gradient first: it is stored as float4)
+            # (ONE split + six views: the slice-then-view form was twelve tensor operations, ~25 us of host time on the path between the capacity
+            #  notification and the backward's launch -- the stretch that decides whether a slower host keeps the GPU fed, tools/host_cprofile.py)
             buf = torch.empty((P * 17,), dtype=torch.float32, device=dev)
-            d_rot = buf[:4 * P].view(P, 4)
-            d_m3 = buf[4 * P:7 * P].view(P, 3)
-            d_m2 = buf[7 * P:10 * P].view(P, 3)
-            d_col = buf[10 * P:13 * P].view(P, 3)
-            d_sc = buf[13 * P:16 * P].view(P, 3)
-            d_op = buf[16 * P:].view(P, 1)
+            b_rot, b_m3, b_m2, b_col, b_sc, b_op = buf.split_with_sizes((4 * P, 3 * P, 3 * P, 3 * P, 3 * P, P))
+            d_rot, d_m3, d_m2 = b_rot.view(P, 4), b_m3.view(P, 3), b_m2.view(P, 3)
+            d_col, d_sc, d_op = b_col.view(P, 3), b_sc.view(P, 3), b_op.view(P, 1)
         if P > 0:
             ext = _ext(rows, 0)
             rc = lib.gsr_backward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
