@@ -1015,3 +1015,64 @@ def test_large_splats_gradients_through_lists_thousands_deep(family):
     # handful of pixels outside the fragility band stop one splat earlier or later than the oracle, each moving the few Gaussians under it
     frac = assert_grad_parity(grads, og, touched, oradii > 0, strict_max_over=16)
     parity_report("large_splats_gradients[%s]" % family, img, oimg, grads, og, solid, touched, visible=oradii > 0)
+
+
+def test_row_interval_binning_never_drops_a_pair_the_per_cell_test_lists():
+    """Rects of more than 32 cells are binned by ROW INTERVALS (gsr_common.h::gsr_row_cells) instead of the per-cell minimum-of-the-quadratic-form test.
+    The claim to hold it to: the interval form lists a SUPERSET of the per-cell test (extra pairs are skipped by the compositor's alpha test, a dropped pair
+    would be visible) and only marginally more.  The per-cell predicate is restated here in fp64 from the exported splat records (centre, conic, opacity, bin
+    rect) and compared with the (Gaussian, bin) pairs the device really listed."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    W = H = 1024
+    g = S.make_uniform_cloud(12000, W, H, seed=77, scale_med=0.05, z_range=(2.0, 6.0), behind_frac=0.0)
+    g["opacities"] = np.clip(g["opacities"], 0.02, 0.95).astype(np.float32)
+    dpix = np.ones((3, H, W), np.float32)
+    img, radii, grads, t = hip_render(g, dpix, debug=True)
+    P = g["means3D"].shape[0]
+    st = RZ.export_state(t["ws"], P, W, H, t["cap"])
+    xy, co, rect = st["xy"].cpu().numpy().astype(np.float64), st["conic_opacity"].cpu().numpy().astype(np.float64), st["rect"].cpu().numpy()
+    rg, plist, bx = st["ranges"].cpu().numpy(), st["point_list"].cpu().numpy(), st["bx"]
+    listed = set()
+    for b, (a_, b_) in enumerate(rg):
+        for i in plist[a_:b_]:
+            listed.add((int(i), b))
+    area = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
+    big = np.flatnonzero(area > 32)
+    assert len(big) > 2000, len(big)
+    must, may = 0, 0
+    missing = []
+    for i in big:
+        x, y = xy[i]
+        A, B, Cc, op = co[i]              # conic (A, B, C) and opacity as the record holds them
+        thr = 2.0 * np.log(255.0 * op)    # alpha >= 1/255  <=>  q <= thr (the device inflates it by 0.2 % + 0.02)
+        x0, y0, x1, y1 = rect[i]
+        for cy_ in range(y0, y1):
+            for cx_ in range(x0, x1):
+                X0, Y0 = 8.0 * cx_, 8.0 * cy_
+                # minimum of q over the bin's pixel-centre rectangle [X0, X0+7] x [Y0, Y0+7] (convex: the centre, or the facing edges)
+                px_, py_ = min(max(x, X0), X0 + 7), min(max(y, Y0), Y0 + 7)
+                if px_ == x and py_ == y:
+                    qmin = 0.0
+                else:
+                    best = np.inf
+                    if px_ != x:
+                        dx = px_ - x
+                        yy = min(max(y - B * dx / Cc, Y0), Y0 + 7)
+                        best = min(best, A * dx * dx + 2 * B * dx * (yy - y) + Cc * (yy - y) ** 2)
+                    if py_ != y:
+                        dy = py_ - y
+                        xx = min(max(x - B * dy / A, X0), X0 + 7)
+                        best = min(best, A * (xx - x) ** 2 + 2 * B * (xx - x) * dy + Cc * dy * dy)
+                    qmin = best
+                pair = (int(i), cy_ * bx + cx_)
+                if qmin <= thr:                       # some pixel of the bin can reach alpha >= 1/255: the pair MUST be listed
+                    must += 1
+                    if pair not in listed:
+                        missing.append((pair, qmin, thr))
+                if pair in listed:
+                    may += 1
+    print({"large_rects": int(len(big)), "pairs_the_exact_test_requires": must, "pairs_listed": may, "excess": may / max(1, must) - 1.0})
+    assert not missing, missing[:5]
+    assert may <= 1.10 * must          # a quarter pixel and the inflated threshold: a few per cent more pairs, never fewer
