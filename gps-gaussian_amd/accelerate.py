@@ -203,16 +203,22 @@ def restore():
             calls[k] = 0
 
 
+_late_calls = 0
+
+
 def late_apply():
     """Safety net for import orders in which no reference module loads after the drop-in (nothing for the finder to hook): the shims call this
-    on first use.  A flag test once everything requested is in place."""
-    global _armed
+    on first use.  A flag test once everything requested is in place -- or after 16 tries: a requested feature whose module the script never imports
+    (`loss` in a pure inference script that does not touch lib.loss) must not cost every later render call a table walk; the finder still catches
+    the module should it load later."""
+    global _armed, _late_calls
     if not _armed:
         return
     apply()
+    _late_calls += 1
     feats = requested()
     want = sum(len(rows) for rows in _table(feats).values())
-    if sum(1 for k in _originals) >= want:
+    if len(_originals) >= want or _late_calls >= 16:
         _armed = False
 
 
