@@ -280,9 +280,10 @@ def install():
 
 
 def uninstall():
-    global _finder, _armed
+    global _finder, _armed, _late_calls
     with _lock:
         _armed = False
+        _late_calls = 0
         if _finder is not None and _finder in sys.meta_path:
             sys.meta_path.remove(_finder)
         _finder = None

@@ -1076,3 +1076,21 @@ def test_row_interval_binning_never_drops_a_pair_the_per_cell_test_lists():
     print({"large_rects": int(len(big)), "pairs_the_exact_test_requires": must, "pairs_listed": may, "excess": may / max(1, must) - 1.0})
     assert not missing, missing[:5]
     assert may <= 1.10 * must          # a quarter pixel and the inflated threshold: a few per cent more pairs, never fewer
+
+
+@pytest.mark.parametrize("scale_modifier,sort_class", [(2.5, "regs_4_waves"), (4.0, "lds_workgroup")])
+def test_full_size_lists_of_thousands_of_keys_are_sorted(scale_modifier, sort_class):
+    """The multi-wave register sort and the LDS workgroup sort AT FULL SIZE: the untrained-heads stereo human (every scale at the clamp) rendered at 2048^2 with
+    scale_modifier 2.5 / 4 -- ~1e8 / ~2.7e8 (Gaussian, bin) instances, bins with lists of 4,097-8,192 / more than 8,192 keys, thousands of them.  debug=True makes
+    the forward validate EVERY list on the device (ids in range, (depth, index) order, scatter cursors at their segment ends) and fail with GPSGS_E_INTERNAL."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_scene(1024, 300000, render_res=2048, attributes="untrained", seed=S.SEED + 5)
+    g["scale_modifier"] = scale_modifier
+    img, radii, _, _ = hip_render(g, debug=True)          # raises if the self-check fails
+    assert np.isfinite(img).all() and (radii > 0).sum() > 250000
+    st = RZ._dev_state(torch.device("cuda:0"))
+    lo, hi = _SORT_CLASSES[sort_class]
+    assert lo <= st["longest"], (st["longest"], sort_class)
+    print({"scale_modifier": scale_modifier, "longest_list": st["longest"], "R": st["last_R"]})
