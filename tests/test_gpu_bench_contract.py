@@ -58,6 +58,11 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02     # whole-job aggregate: both ranks' views / the slowest rank's time
     assert d["cpu_baseline"] is None                  # rank 0 at N = 1 only
     assert d["stage2_path"]["n_gpus"] == 2 and d["stage2_path"]["iters_per_s"] > 0
+    # round 4: the exchange step is also timed on its own, rank 0 says what an N > 1 run does not measure, and every rank was given its own CPU slice
+    assert d["stage2_path"]["allreduce_alone_ms"] > 0
+    assert set(d["not_measured_at_this_world_size"]) >= {"configs", "full_pipeline", "cpu_baseline", "hip_graph_replay"}
+    assert d["configs"] is None and d["full_pipeline"] is None and d["hip_graph_replay"] is None
+    assert isinstance(d["cpu_affinity"], (dict, str))
 
 
 def test_plain_command_with_gpus_2_starts_two_ranks():
@@ -93,3 +98,4 @@ def test_world_1_through_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["stage2_path"]["allreduce"].startswith("nccl, world 1 (forced"), d["stage2_path"]
+    assert d["stage2_path"]["allreduce_alone_ms"] > 0 and d["not_measured_at_this_world_size"] == []   # the 20.6 MB RCCL all-reduce on its own
