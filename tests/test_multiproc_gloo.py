@@ -98,3 +98,46 @@ def test_two_rank_protocol_and_grad_allreduce(tmp_path):
     assert len(lines) == 1                      # exactly one JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["views"] == list(range(7))
+
+
+def test_cpulist_parser_and_affinity_without_topology():
+    import gps_gaussian_amd  # noqa: F401
+    from gps_gaussian_amd import dist as D
+    assert D._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and D._parse_cpulist("") == set()
+    assert D.gpu_numa_cpus(0) is None or isinstance(D.gpu_numa_cpus(0), set)      # no GPU here: "the platform does not say"
+    assert D.set_cpu_affinity(0, 1) is None                                        # one rank: left alone
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        env = os.environ.pop("GPSGS_AFFINITY", None)
+        got = []
+        for r in (0, 1):                                                            # two ranks (each its own process in real life), no topology:
+            os.sched_setaffinity(0, before)                                         # an even split of what the process may run on
+            got.append(D.set_cpu_affinity(r, 2))
+        os.sched_setaffinity(0, before)
+        if len(before) >= 2:
+            assert got[0] and got[1] and not (got[0] & got[1]) and (got[0] | got[1]) <= set(before)
+        os.environ["GPSGS_AFFINITY"] = "0"
+        assert D.set_cpu_affinity(0, 2) is None                                    # switched off
+    finally:
+        os.sched_setaffinity(0, before)
+        os.environ.pop("GPSGS_AFFINITY", None)
+        if env is not None:
+            os.environ["GPSGS_AFFINITY"] = env
+
+
+def test_full_pipeline_leg_respects_its_time_budget():
+    """bench.py's `full_pipeline` leg (BASELINE configs 3 / 4 in child processes) must never run past its budget: with no time left every entry says it was
+    skipped -- and why -- instead of starting a full-size network run; without a reference build it says so."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.full_pipeline_leg(1.0)
+    if "skipped" in out:                      # no reference staged in this checkout
+        assert out["measured_in_this_run"] is False and "reference" in out["skipped"]
+        return
+    legs = [k for k in out if k.startswith("config")]
+    assert len(legs) == 4
+    for k in legs:
+        assert out[k]["measured_in_this_run"] is False and "budget" in out[k]["skipped"], out[k]
+    assert out["miopen_find_mode"] in ("FAST", os.environ.get("MIOPEN_FIND_MODE", "FAST"))
