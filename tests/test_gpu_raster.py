@@ -1088,9 +1088,20 @@ def test_full_size_lists_of_thousands_of_keys_are_sorted(scale_modifier, sort_cl
     from gps_gaussian_amd import synthetic as S
     g = S.make_scene(1024, 300000, render_res=2048, attributes="untrained", seed=S.SEED + 5)
     g["scale_modifier"] = scale_modifier
-    img, radii, _, _ = hip_render(g, debug=True)          # raises if the self-check fails
-    assert np.isfinite(img).all() and (radii > 0).sum() > 250000
     st = RZ._dev_state(torch.device("cuda:0"))
-    lo, hi = _SORT_CLASSES[sort_class]
-    assert lo <= st["longest"], (st["longest"], sort_class)
-    print({"scale_modifier": scale_modifier, "longest_list": st["longest"], "R": st["last_R"]})
+    keep = {k: st.get(k) for k in ("ratio", "floor", "longest", "big_bins", "last_points", "last_R")}
+    try:
+        img, radii, _, _ = hip_render(g, debug=True)          # raises if the self-check fails
+        assert np.isfinite(img).all() and (radii > 0).sum() > 250000
+        lo, hi = _SORT_CLASSES[sort_class]
+        assert lo <= st["longest"], (st["longest"], sort_class)
+        print({"scale_modifier": scale_modifier, "longest_list": st["longest"], "R": st["last_R"]})
+    finally:
+        # the capacity policy is sticky by design (a training process keeps the largest workspace it ever needed); the rest of the suite should not inherit
+        # the ~600 instances per Gaussian of this scene
+        for k, v in keep.items():
+            if v is None:
+                st.pop(k, None)
+            else:
+                st[k] = v
+        torch.cuda.empty_cache()
