@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--render-res", type=int, default=None)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "wg_trace.npz"))
     ap.add_argument("--hint", type=int, default=None)
+    ap.add_argument("--attributes", default="trained", help="'untrained': every scale at the 0.01 m clamp (the large-splat regime)")
     ap.add_argument("--no-priority", action="store_true", help="render without GSR_FLAG_WAVE_PRIORITY (the session's default is on)")
     args = ap.parse_args()
     import torch
@@ -98,7 +99,7 @@ def main():
     from gps_gaussian_amd.session import RasterSession
     dev = torch.device("cuda:0")
     rr = args.render_res or args.res
-    smp = S.make_stereo_sample(args.res, args.gaussians, seed=S.SEED, render_res=rr)
+    smp = S.make_stereo_sample(args.res, args.gaussians, seed=S.SEED, render_res=rr, attributes=args.attributes)
     g, cam = S.compact_sample(smp), smp["novel_view"]
     t = {k: torch.from_numpy(g[k]).to(dev) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     P = t["means3D"].shape[0]
