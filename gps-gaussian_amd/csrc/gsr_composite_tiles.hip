@@ -319,8 +319,15 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
 }
 
 // ~170 VGPRs: 2 waves per SIMD (2 and 3 measured identical: the kernel is VALU-issue bound; forcing 4 spills: 172 us)
+// The instantiation WITHOUT dL/dcolour (GSR_FLAG_NO_COLOR_GRAD: the gradient set stage 2 differentiates) needs 139 VGPRs on its own = 3 waves per SIMD; asked for 4
+// the compiler fits it into 128 with 3 spilled dwords.  Where the kernel is THROUGHPUT-bound -- ~19 waves per SIMD, 95 % SIMD utilisation: config 2 rendered at 2048^2
+// (what stage 2 renders), config 5, the large-splat regime (profiles/r04_regime_wg_timeline.md) -- the fourth wave pays: 183.7 -> 165.4 / 587.4 -> 554.9 / 669.0 -> 627.0 us;
+// at config 2 (five work items per SIMD, latency-bound) nothing changes (106.7 -> 107.1).  Same instructions, same results.
+#ifndef GSR_BWD_NOCOLOR_WAVES
+#define GSR_BWD_NOCOLOR_WAVES 4
+#endif
 template <bool CG>
-__global__ __launch_bounds__(64, 2) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+__global__ __launch_bounds__(64, CG ? 2 : GSR_BWD_NOCOLOR_WAVES) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
