@@ -117,8 +117,11 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
     }
 }
 
+#ifndef GSR_FWD_WAVES
+#define GSR_FWD_WAVES 5  // waves per SIMD asked of the compiler (92 VGPRs fit 5)
+#endif
 template <bool KEEP>
-__global__ __launch_bounds__(64, 5) void k_composite_fwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
+__global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             float *__restrict__ out_color, float *__restrict__ final_T,
