@@ -619,8 +619,11 @@ __device__ __forceinline__ void sort_multi(const uint64_t *__restrict__ seg, uin
 
 // A persistent grid strides over the BUSY bins in work order (wg_order: the longest lists first, so the stride deals them out evenly) and
 // sorts those whose length falls into this launch's class: (1024 << (NW/2)) < n <= 2048 * NW ... i.e. NW = 1: 1,025-2,048, 2: -4,096, 4: -8,192.
+#ifndef GSR_SORT_MULTI_WAVES
+#define GSR_SORT_MULTI_WAVES 3  // waves per SIMD asked of the compiler for the one- and two-wave classes (168 VGPRs)
+#endif
 template <int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 2 : 3))) void k_sort_multi(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 2 : GSR_SORT_MULTI_WAVES))) void k_sort_multi(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                         const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                         const GsrHeader *__restrict__ hdr) {
     __shared__ uint64_t xch[NW > 1 ? NW * 64 * SM_KPL : 1];
