@@ -127,7 +127,7 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
                                                                    rs_proto.bg, math.tan(float(cam["FovX"]) * 0.5), math.tan(float(cam["FovY"]) * 0.5), 1.0),
                           gout=torch.randn(3, render_res, render_res, device=dev)))
 
-    def run(kind, n, k):  # k steps, n views in flight
+    def run(kind, n, k, color_grad=True):  # k steps, n views in flight
         while k > 0:
             m = min(n, k)
             for L in lanes[:m]:
@@ -136,7 +136,7 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
             for L in lanes[:m]:
                 L[kind].forward_end()
                 if kind == "train":
-                    L[kind].backward(L["gout"], stream=L["stream"])
+                    L[kind].backward(L["gout"], color_grad=color_grad, stream=L["stream"])
             k -= m
 
     out = {"P": int(lanes[0]["a"][0].shape[0]), "render": "%dx%d" % (render_res, render_res), "steps": steps, "blocks": 3}
@@ -150,6 +150,12 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
             out[label][nl] = {"views_per_s": round(steps / el, 1), "ms_per_view": round(el / steps * 1e3, 4),
                               "blocks_ms_per_view": [round(x / steps * 1e3, 4) for x in els],
                               "workspace_reallocations_while_timed": sum(L[kind].allocations for L in lanes) - allocs0}
+    # the gradient set stage 2 differentiates (no dL/dcolour: the colours are input pixels) -- its backward instantiation keeps four waves per SIMD
+    out["fwd_bwd_stage2_gradient_set"] = {}
+    for n, nl in ((1, "one_view_in_flight"), (inflight, "%d_views_in_flight" % inflight)):
+        run("train", n, 2 * n + 3, color_grad=False)
+        els = sorted(timed(lambda k, n=n: run("train", n, k, color_grad=False), steps, 0, multi=True) for _ in range(3))
+        out["fwd_bwd_stage2_gradient_set"][nl] = {"views_per_s": round(steps / els[1], 1), "ms_per_view": round(els[1] / steps * 1e3, 4)}
     out["R"] = R = int(RZ.last_stats(dev).get("last_R", 0))
     if stage_table:
         # per-kernel durations of THIS workload, one view at a time (every launch has the chip to itself), and each kernel's algorithmic HBM
