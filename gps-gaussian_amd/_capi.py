@@ -36,8 +36,11 @@ class GsrHeader(C.Structure):
 
 
 class GsrViewExt(C.Structure):
-    """Optional extras of one view (include/gpsgs.h): device pointer to the {begin, end} row range, work-order hint."""
-    _fields_ = [("row_range", C.c_void_p), ("order_hint", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+    """Optional extras of one view (include/gpsgs.h): device pointer to the {begin, end} row range, work-order hint, and (ABI 3) the SH-colour /
+    precomputed-covariance inputs of the upstream interface with their gradient outputs."""
+    _fields_ = [("row_range", C.c_void_p), ("order_hint", C.c_uint32), ("sh_degree", C.c_uint32), ("sh_coeffs", C.c_uint32), ("reserved0", C.c_uint32),
+                ("shs", C.c_void_p), ("campos", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+                ("reserved", C.c_uint32 * 4)]
 
 
 _lib = None
@@ -127,7 +130,7 @@ def lib():
     l.cu_upsample_backward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.cu_upsample_scratch_bytes.restype = sz
     l.cu_upsample_scratch_bytes.argtypes = [i32, i32, i32, i32]
-    if l.gpsgs_abi_version() != 2:
+    if l.gpsgs_abi_version() != 3:
         raise ImportError("gps_gaussian_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = l
     return l

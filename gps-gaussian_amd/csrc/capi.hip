@@ -134,8 +134,12 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     if (P < 0 || width <= 0 || height <= 0 || instance_capacity < 0 || instance_capacity > 0x7fffffffLL) return GPSGS_E_INVALID;
     if (width > 65535 * GSR_TILE || height > 65535 * GSR_TILE) return GPSGS_E_INVALID;
     if (!out_color || !workspace) return GPSGS_E_INVALID;
-    if (P > 0 && (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !projmatrix || !bg || !radii))
-        return GPSGS_E_INVALID;
+    const float *shs = ext ? ext->shs : nullptr, *cov3D_precomp = ext ? ext->cov3D_precomp : nullptr;
+    if (P > 0 && (!means3D || !opacities || !viewmatrix || !projmatrix || !bg || !radii)) return GPSGS_E_INVALID;
+    // exactly one of (colors, shs) and exactly one of (scales + rotations, cov3D_precomp): upstream's GaussianRasterizer.forward raises on both
+    if (P > 0 && ((shs != nullptr) == (colors != nullptr) || (cov3D_precomp != nullptr) == (scales != nullptr && rotations != nullptr))) return GPSGS_E_INVALID;
+    if (P > 0 && cov3D_precomp && (scales || rotations)) return GPSGS_E_INVALID;
+    if (shs && (!ext->campos || ext->sh_degree > 3u || ext->sh_coeffs > 16u || (ext->sh_degree + 1u) * (ext->sh_degree + 1u) > ext->sh_coeffs)) return GPSGS_E_INVALID;
     const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
     if (workspace_bytes < L.total_fwd) return GPSGS_E_WORKSPACE;  // the backward tail is optional for a forward
     hipStream_t s = (hipStream_t)stream;
@@ -175,6 +179,8 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     q.scale_modifier = scale_modifier; q.tanfovx = tanfovx; q.tanfovy = tanfovy;
     q.view = viewmatrix; q.proj = projmatrix; q.bg = bg; q.out_color = out_color; q.radii = radii; q.cap = instance_capacity;
     q.row_range = row_range;
+    q.shs = shs; q.campos = shs ? ext->campos : nullptr; q.cov3D_precomp = cov3D_precomp;
+    q.sh_degree = shs ? ext->sh_degree : 0u; q.sh_coeffs = shs ? ext->sh_coeffs : 0u;
     // a workspace that includes the backward tail gets the per-Gaussian slot prefix and cleared record flags from the forward
     const bool training = workspace_bytes >= L.total;
     q.goff = training ? reinterpret_cast<uint32_t *>(at(workspace, L.goff)) : nullptr;
@@ -275,8 +281,11 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
     (void)colors; (void)opacities;  // already folded into the splat records of the workspace
     if (P < 0 || width <= 0 || height <= 0 || instance_capacity < 0) return GPSGS_E_INVALID;
     if (P == 0) return GPSGS_OK;
-    if (!means3D || !scales || !rotations || !viewmatrix || !projmatrix || !bg || !radii || !dL_dpix || !dL_dmeans3D || !dL_dmeans2D ||
-        !dL_dcolors || !dL_dopacity || !dL_dscales || !dL_drotations || !workspace)
+    const float *shs = ext ? ext->shs : nullptr, *cov3D_precomp = ext ? ext->cov3D_precomp : nullptr;
+    if (!means3D || !viewmatrix || !projmatrix || !bg || !radii || !dL_dpix || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !workspace) return GPSGS_E_INVALID;
+    if (!shs && !dL_dcolors) return GPSGS_E_INVALID;
+    if (cov3D_precomp ? (!ext->dL_dcov3D || scales || rotations) : (!scales || !rotations || !dL_dscales || !dL_drotations)) return GPSGS_E_INVALID;
+    if (shs && (!ext->campos || !ext->dL_dsh || ext->sh_degree > 3u || ext->sh_coeffs > 16u || (ext->sh_degree + 1u) * (ext->sh_degree + 1u) > ext->sh_coeffs))
         return GPSGS_E_INVALID;
     const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
     if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
@@ -316,6 +325,9 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
     b.dL_dmeans3D = dL_dmeans3D; b.dL_dmeans2D = dL_dmeans2D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations;
     b.row_range = ext ? ext->row_range : nullptr;
+    b.shs = shs; b.campos = shs ? ext->campos : nullptr; b.cov3D_precomp = cov3D_precomp;
+    b.sh_degree = shs ? ext->sh_degree : 0u; b.sh_coeffs = shs ? ext->sh_coeffs : 0u;
+    b.dL_dsh = shs ? ext->dL_dsh : nullptr; b.dL_dcov3D = cov3D_precomp ? ext->dL_dcov3D : nullptr;
     {
         trace("preprocess_bwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);

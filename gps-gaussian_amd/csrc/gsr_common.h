@@ -434,6 +434,9 @@ struct GsrFwdParams {
     int64_t cap;
     uint32_t *goff, *gpart;  // backward tail of the workspace (NULL for a forward-only workspace)
     const uint32_t *row_range;  // device {begin, end} or NULL: the view's Gaussians are rows [begin, end) of the batch-wide arrays, P = capacity
+    // the other half of the upstream interface (GsrViewExt): SH colours instead of `colors`, precomputed covariances instead of scales + rotations
+    const float *shs, *campos, *cov3D_precomp;  // [rows, sh_coeffs, 3], [3], [rows, 6]; NULL = not used
+    uint32_t sh_degree, sh_coeffs;
 };
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
@@ -480,6 +483,9 @@ struct GsrBwdParams {
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dscales, *dL_drotations;
     const uint32_t *row_range;  // as in GsrFwdParams
     uint32_t flags_first_min;   // runs of more gradient-record slots than this read their flags before their records (k_preprocess_bwd); ~0u: chosen per view
+    const float *shs, *campos, *cov3D_precomp;  // as in GsrFwdParams
+    uint32_t sh_degree, sh_coeffs;
+    float *dL_dsh, *dL_dcov3D;  // [rows, sh_coeffs, 3], [rows, 6]: written when the matching input is given
 };
 
 #if defined(__HIPCC__)

@@ -88,6 +88,78 @@ __device__ __forceinline__ void cov2d(const Ewa &e, const float c6[6], float &a,
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+
+// ---- spherical-harmonics colours (the `shs` input of the upstream interface; the reference itself passes colors_precomp,
+// /root/reference/gaussian_renderer/__init__.py:54-62, and constructs the settings with sh_degree = 3 and campos at :46-47) -----------------
+// colour = max(sum_k basis_k(dir) sh[k] + 0.5, 0), dir = (mean - campos) normalised; basis = the published real SH basis of the 3D-Gaussian-
+// splatting rasteriser up to degree 3 (the CPU checker restates the same; the tests pin both against torch autograd).
+constexpr float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f, SH_C2_3 = -1.0925484305920792f,
+                SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f, SH_C3_3 = 0.3731763325901154f,
+                SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f, SH_C3_6 = -0.5900435899266435f;
+
+__device__ __forceinline__ int sh_basis(int deg, float x, float y, float z, float b[16]) {
+    b[0] = SH_C0;
+    if (deg < 1) return 1;
+    b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    if (deg < 2) return 4;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.f * zz - xx - yy); b[7] = SH_C2_3 * xz; b[8] = SH_C2_4 * (xx - yy);
+    if (deg < 3) return 9;
+    b[9] = SH_C3_0 * y * (3.f * xx - yy);
+    b[10] = SH_C3_1 * xy * z;
+    b[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+    b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+    b[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+    b[14] = SH_C3_5 * z * (xx - yy);
+    b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+    return 16;
+}
+// d basis_k / d(x, y, z), the direction's components taken as free variables (the normalisation follows in the caller)
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float d[16][3]) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) { d[k][0] = 0.f; d[k][1] = 0.f; d[k][2] = 0.f; }
+    if (deg < 1) return;
+    d[1][1] = -SH_C1; d[2][2] = SH_C1; d[3][0] = -SH_C1;
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    d[4][0] = SH_C2_0 * y; d[4][1] = SH_C2_0 * x;
+    d[5][1] = SH_C2_1 * z; d[5][2] = SH_C2_1 * y;
+    d[6][0] = SH_C2_2 * -2.f * x; d[6][1] = SH_C2_2 * -2.f * y; d[6][2] = SH_C2_2 * 4.f * z;
+    d[7][0] = SH_C2_3 * z; d[7][2] = SH_C2_3 * x;
+    d[8][0] = SH_C2_4 * 2.f * x; d[8][1] = SH_C2_4 * -2.f * y;
+    if (deg < 3) return;
+    d[9][0] = SH_C3_0 * 6.f * xy; d[9][1] = SH_C3_0 * 3.f * (xx - yy);
+    d[10][0] = SH_C3_1 * yz; d[10][1] = SH_C3_1 * xz; d[10][2] = SH_C3_1 * xy;
+    d[11][0] = SH_C3_2 * -2.f * xy; d[11][1] = SH_C3_2 * (4.f * zz - xx - 3.f * yy); d[11][2] = SH_C3_2 * 8.f * yz;
+    d[12][0] = SH_C3_3 * -6.f * xz; d[12][1] = SH_C3_3 * -6.f * yz; d[12][2] = SH_C3_3 * 3.f * (2.f * zz - xx - yy);
+    d[13][0] = SH_C3_4 * (4.f * zz - 3.f * xx - yy); d[13][1] = SH_C3_4 * -2.f * xy; d[13][2] = SH_C3_4 * 8.f * xz;
+    d[14][0] = SH_C3_5 * 2.f * xz; d[14][1] = SH_C3_5 * -2.f * yz; d[14][2] = SH_C3_5 * (xx - yy);
+    d[15][0] = SH_C3_6 * 3.f * (xx - yy); d[15][1] = SH_C3_6 * -6.f * xy;
+}
+// colour of one Gaussian from its coefficients sh[M][3] (row r of the batch-wide array); clamp[ch] = the sum was negative (gradient cut).
+// Evaluated by the forward AND re-evaluated by the backward (same code, same uncontracted arithmetic, same translation unit: identical clamp
+// decisions) instead of keeping 3 flags per Gaussian in the workspace.
+__device__ __forceinline__ void sh_color(int deg, const float *__restrict__ sh, const float p[3], const float *__restrict__ campos, float rgb[3],
+                                         bool clamp[3], float dir[3], float raw[3]) {
+    raw[0] = p[0] - campos[0]; raw[1] = p[1] - campos[1]; raw[2] = p[2] - campos[2];
+    const float len = sqrtf(raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2]);
+    dir[0] = raw[0] / len; dir[1] = raw[1] / len; dir[2] = raw[2] / len;
+    float b[16];
+    const int n = sh_basis(deg, dir[0], dir[1], dir[2], b);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++)  // (unrolled with a guard: the basis stays in registers)
+            if (k < n) v += b[k] * sh[3 * k + ch];
+        v += 0.5f;
+        clamp[ch] = v < 0.f;
+        rgb[ch] = v < 0.f ? 0.f : v;
+    }
+}
+
 // The (Gaussian, bin) predicate of the COUNT pass: small rects (<= 32 cells) are tested per cell and the outcomes kept as a bit mask for k_scatter;
 // large rects go by row intervals (gsr_row_cells) when the conic allows, per cell otherwise -- k_scatter re-derives either from the record
 // and the threshold stored in the mask word (gsr_masked_hit).
@@ -109,6 +181,10 @@ struct CountHit {
     }
 };
 
+// APPEAR = false: the inputs the reference passes (precomputed colours, scale + rotation): the instantiation every measured configuration runs.
+// APPEAR = true: SH colours (q.shs) and / or precomputed 3D covariances (q.cov3D_precomp) -- its own instantiation, so that the common one carries
+// neither the branches nor the registers of these inputs.
+template <bool APPEAR>
 __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint32_t *__restrict__ hitmask,
                                                                uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_count,
                                                                GsrHeader *__restrict__ hdr) {
@@ -140,12 +216,18 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     const size_t r = (size_t)row0 + (size_t)i;
     const Cam cam = load_cam(q.view, q.proj);
     const float p[3] = {q.means3D[3 * r], q.means3D[3 * r + 1], q.means3D[3 * r + 2]};
-    const float col[3] = {q.colors[3 * r], q.colors[3 * r + 1], q.colors[3 * r + 2]};
+    const bool use_sh = APPEAR && q.shs != nullptr, use_cov = APPEAR && q.cov3D_precomp != nullptr;  // wave-uniform
+    float col[3] = {0.f, 0.f, 0.f};
+    if (!use_sh) { col[0] = q.colors[3 * r]; col[1] = q.colors[3 * r + 1]; col[2] = q.colors[3 * r + 2]; }
     const float op = q.opacities[r];
     // rotation and scale are fetched up front, together with the other inputs (one memory round trip instead of a second one
     // behind the near-plane test; a culled Gaussian wastes 28 bytes)
-    float4 rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * r);
-    float s_raw[3] = {q.scales[3 * r], q.scales[3 * r + 1], q.scales[3 * r + 2]};
+    float4 rot = make_float4(1.f, 0.f, 0.f, 0.f);
+    float s_raw[3] = {0.f, 0.f, 0.f};
+    if (!use_cov) {
+        rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * r);
+        s_raw[0] = q.scales[3 * r]; s_raw[1] = q.scales[3 * r + 1]; s_raw[2] = q.scales[3 * r + 2];
+    }
     // keep the compiler from sinking these loads back behind the branch
     __asm__ volatile("" : "+v"(rot.x), "+v"(rot.y), "+v"(rot.z), "+v"(rot.w), "+v"(s_raw[0]), "+v"(s_raw[1]), "+v"(s_raw[2]));
     const float sc[3] = {q.scale_modifier * s_raw[0], q.scale_modifier * s_raw[1], q.scale_modifier * s_raw[2]};
@@ -167,8 +249,13 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
         const float fx = (float)q.W / (2.f * q.tanfovx), fy = (float)q.H / (2.f * q.tanfovy);
 
         float R[3][3], c6[6];
-        quat_to_R(rot.x, rot.y, rot.z, rot.w, R);
-        cov3d(sc, R, c6);
+        if (use_cov) {  // the covariance is an input (upper triangle xx, xy, xz, yy, yz, zz), used as given: scale_modifier does not apply
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = q.cov3D_precomp[6 * r + k];
+        } else {
+            quat_to_R(rot.x, rot.y, rot.z, rot.w, R);
+            cov3d(sc, R, c6);
+        }
         const Ewa e = ewa_setup(pv, cam.v, fx, fy, q.tanfovx, q.tanfovy);
         float a, b, c;
         cov2d(e, c6, a, b, c);
@@ -191,6 +278,12 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
                 o0 = make_float4(px, py, c * det_inv, -b * det_inv);
                 o1.x = a * det_inv;
                 o2y = pv[2];
+                if (use_sh) {  // only a visible Gaussian gets a colour evaluated (upstream preprocessCUDA does the same)
+                    bool cl[3];
+                    float dir[3], raw[3], rgb[3];
+                    sh_color((int)q.sh_degree, q.shs + (size_t)3 * q.sh_coeffs * r, p, q.campos, rgb, cl, dir, raw);
+                    o1.z = rgb[0]; o1.w = rgb[1]; o2x = rgb[2];
+                }
                 // Bin rect = (upstream's 16x16-tile rect, in 8-px bins) INTERSECT (bounding box of the alpha >= 1/255
                 // level set).  alpha = op * exp(power) >= 1/255  <=>  d^T Sigma^-1 d <= 2 ln(255 op) =: 2 tau, whose
                 // axis-aligned extent is |dx| <= sqrt(2 tau a), |dy| <= sqrt(2 tau c) with (a,b,c) the dilated 2D
@@ -258,6 +351,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     if (i < q.P) hitmask[i] = mask;
 }
 
+template <bool APPEAR>  // as k_preprocess: true = SH colours and / or precomputed covariances among the inputs
 __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrSplat *__restrict__ splats,
                                                         const uint32_t *__restrict__ goff, const uint32_t *__restrict__ gpart,
                                                         const uint8_t *__restrict__ inst_valid, const float *__restrict__ inst_dop,
@@ -273,12 +367,19 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
     const bool rendered = hdr->overflow == 0u;
     float dm[3] = {0.f, 0.f, 0.f}, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     float dcol[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dop = 0.f;
+    const bool use_sh = APPEAR && q.shs != nullptr, use_cov = APPEAR && q.cov3D_precomp != nullptr;  // wave-uniform
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool sh_written = false;
     if (rendered && q.radii[r] > 0) {
         const Cam cam = load_cam(q.view, q.proj);
         // the per-Gaussian inputs of the chain rule are requested BEFORE the record gather, so they travel alongside it
         float in_p[3] = {q.means3D[3 * r], q.means3D[3 * r + 1], q.means3D[3 * r + 2]};
-        float4 in_rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * r);
-        float in_s[3] = {q.scales[3 * r], q.scales[3 * r + 1], q.scales[3 * r + 2]};
+        float4 in_rot = make_float4(1.f, 0.f, 0.f, 0.f);
+        float in_s[3] = {0.f, 0.f, 0.f};
+        if (!use_cov) {
+            in_rot = *reinterpret_cast<const float4 *>(q.rotations + 4 * r);
+            in_s[0] = q.scales[3 * r]; in_s[1] = q.scales[3 * r + 1]; in_s[2] = q.scales[3 * r + 2];
+        }
         __asm__ volatile("" : "+v"(in_p[0]), "+v"(in_p[1]), "+v"(in_p[2]), "+v"(in_rot.x), "+v"(in_rot.y), "+v"(in_rot.z), "+v"(in_rot.w),
                          "+v"(in_s[0]), "+v"(in_s[1]), "+v"(in_s[2]));
         // gather this Gaussian's instance records in rect order: fixed summation order -> reproducible gradients
@@ -357,8 +458,17 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const float4 rot = in_rot;
         const float sv[3] = {q.scale_modifier * in_s[0], q.scale_modifier * in_s[1], q.scale_modifier * in_s[2]};
         float Rm[3][3], c6[6];
-        quat_to_R(rot.x, rot.y, rot.z, rot.w, Rm);
-        cov3d(sv, Rm, c6);
+        if (use_cov) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = q.cov3D_precomp[6 * r + k];
+#pragma unroll
+            for (int a_ = 0; a_ < 3; a_++)
+#pragma unroll
+                for (int b_ = 0; b_ < 3; b_++) Rm[a_][b_] = 0.f;
+        } else {
+            quat_to_R(rot.x, rot.y, rot.z, rot.w, Rm);
+            cov3d(sv, Rm, c6);
+        }
         float pv[3];
         pv[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
         pv[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
@@ -420,7 +530,47 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         dm[1] += (pr[4] * mw - pr[7] * mul1) * dm2[0] + (pr[5] * mw - pr[7] * mul2) * dm2[1];
         dm[2] += (pr[8] * mw - pr[11] * mul1) * dm2[0] + (pr[9] * mw - pr[11] * mul2) * dm2[1];
 
+        if (use_sh) {
+            // colour -> SH coefficients, and -> mean3D through the view direction (upstream computeColorFromSH backward): the colour and its
+            // clamp decisions are re-evaluated exactly as the forward did
+            bool cl[3];
+            float dir[3], raw[3], rgb[3], bs[16], dbs[16][3];
+            const float *sh = q.shs + (size_t)3 * q.sh_coeffs * r;
+            sh_color((int)q.sh_degree, sh, p, q.campos, rgb, cl, dir, raw);
+            const int nb = sh_basis((int)q.sh_degree, dir[0], dir[1], dir[2], bs);
+            sh_basis_grad((int)q.sh_degree, dir[0], dir[1], dir[2], dbs);
+            const float dRGB[3] = {cl[0] ? 0.f : dcol[0], cl[1] ? 0.f : dcol[1], cl[2] ? 0.f : dcol[2]};
+            float ddir[3] = {0.f, 0.f, 0.f};
+            float *out = q.dL_dsh + (size_t)3 * q.sh_coeffs * r;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {  // sh_coeffs <= 16 (checked at the C-ABI); unrolled with guards: bs / dbs stay in registers
+                if (k < (int)q.sh_coeffs) {
+                    const bool act = k < nb;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        out[3 * k + ch] = act ? bs[k] * dRGB[ch] : 0.f;  // coefficients beyond the active degree: exact zeros
+                        if (act) {
+                            const float shv = sh[3 * k + ch];
+#pragma unroll
+                            for (int j = 0; j < 3; j++) ddir[j] += dbs[k][j] * shv * dRGB[ch];
+                        }
+                    }
+                }
+            }
+            sh_written = true;
+            const float sum2 = raw[0] * raw[0] + raw[1] * raw[1] + raw[2] * raw[2];
+            const float invsum32 = 1.f / sqrtf(sum2 * sum2 * sum2);
+            dm[0] += ((sum2 - raw[0] * raw[0]) * ddir[0] - raw[1] * raw[0] * ddir[1] - raw[2] * raw[0] * ddir[2]) * invsum32;
+            dm[1] += (-raw[0] * raw[1] * ddir[0] + (sum2 - raw[1] * raw[1]) * ddir[1] - raw[2] * raw[1] * ddir[2]) * invsum32;
+            dm[2] += (-raw[0] * raw[2] * ddir[0] - raw[1] * raw[2] * ddir[1] + (sum2 - raw[2] * raw[2]) * ddir[2]) * invsum32;
+        }
+        if (use_cov) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) dcov[k] = dc6[k];  // upstream's dL_dcov3D: the off-diagonal entries carry both symmetric positions
+        }
+
         // cov3D -> scale, rotation: Sigma = R D R^T, D = diag(s^2); dL/dR = 2 G R D; dL/ds_k = 2 s_k (R^T G R)_kk
+        // (with a precomputed covariance Rm = 0 and sv = 0: the results below are zeros and are not stored)
         const float Gs[3][3] = {{dc6[0], 0.5f * dc6[1], 0.5f * dc6[2]},
                                 {0.5f * dc6[1], dc6[3], 0.5f * dc6[4]},
                                 {0.5f * dc6[2], 0.5f * dc6[4], dc6[5]}};
@@ -445,10 +595,19 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
     const size_t i3 = 3 * r;
     q.dL_dmeans3D[i3] = dm[0]; q.dL_dmeans3D[i3 + 1] = dm[1]; q.dL_dmeans3D[i3 + 2] = dm[2];
     q.dL_dmeans2D[i3] = dm2[0]; q.dL_dmeans2D[i3 + 1] = dm2[1]; q.dL_dmeans2D[i3 + 2] = 0.f;
-    q.dL_dcolors[i3] = dcol[0]; q.dL_dcolors[i3 + 1] = dcol[1]; q.dL_dcolors[i3 + 2] = dcol[2];
+    if (!APPEAR || q.dL_dcolors) { q.dL_dcolors[i3] = dcol[0]; q.dL_dcolors[i3 + 1] = dcol[1]; q.dL_dcolors[i3 + 2] = dcol[2]; }
     q.dL_dopacity[r] = dop;
-    q.dL_dscales[i3] = dsc[0]; q.dL_dscales[i3 + 1] = dsc[1]; q.dL_dscales[i3 + 2] = dsc[2];
-    *reinterpret_cast<float4 *>(q.dL_drotations + 4 * r) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    if (!use_cov) {
+        q.dL_dscales[i3] = dsc[0]; q.dL_dscales[i3 + 1] = dsc[1]; q.dL_dscales[i3 + 2] = dsc[2];
+        *reinterpret_cast<float4 *>(q.dL_drotations + 4 * r) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) q.dL_dcov3D[6 * r + k] = dcov[k];
+    }
+    if (use_sh && !sh_written) {  // invisible (or an overflowed forward): exact zeros, like every other gradient of this Gaussian
+        float *out = q.dL_dsh + (size_t)3 * q.sh_coeffs * r;
+        for (int k = 0; k < 3 * (int)q.sh_coeffs; k++) out[k] = 0.f;
+    }
 }
 
 }  // namespace
@@ -456,7 +615,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
                            hipStream_t s) {
     if (p.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess, dim3((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, p, splats, hitmask, wg_tab, bin_count, hdr);
+    const dim3 grid((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), block(GSR_BIN_THREADS);
+    if (p.shs || p.cov3D_precomp) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, p, splats, hitmask, wg_tab, bin_count, hdr);
+    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, p, splats, hitmask, wg_tab, bin_count, hdr);
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
@@ -467,5 +628,8 @@ void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, co
     static long thr = -2;  // GPSGS_DEBUG_FLAGS_FIRST=<slots>: development knob for the threshold of the flags-first gather (unset: chosen per view)
     if (thr == -2) { const char *e = getenv("GPSGS_DEBUG_FLAGS_FIRST"); thr = e ? atol(e) : -1; }
     q.flags_first_min = thr < 0 ? 0xffffffffu : (uint32_t)thr;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    if (q.shs || q.cov3D_precomp)
+        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    else
+        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }

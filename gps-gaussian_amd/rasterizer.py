@@ -357,10 +357,20 @@ class _Rows:
         self.ptr = offsets.data_ptr() + 4 * self.index
 
 
-def _ext(rows, hint):
+def _ext(rows, hint, appear=None):
+    """appear: None, or (shs, sh_degree, campos, cov3D_precomp, dL_dsh, dL_dcov3D) tensors / None -- the SH-colour and precomputed-covariance
+    inputs (and, for the backward, their gradient arrays)."""
     e = _capi.GsrViewExt()
     e.row_range = rows.ptr if rows is not None else None
     e.order_hint = int(hint) & 0xffffffff
+    if appear is not None:
+        shs, deg, campos, cov, d_sh, d_cov = appear
+        if shs is not None:
+            e.shs, e.sh_degree, e.sh_coeffs, e.campos = shs.data_ptr(), int(deg), int(shs.shape[1]), campos.data_ptr()
+            e.dL_dsh = d_sh.data_ptr() if d_sh is not None else None
+        if cov is not None:
+            e.cov3D_precomp = cov.data_ptr()
+            e.dL_dcov3D = d_cov.data_ptr() if d_cov is not None else None
     return e
 
 
@@ -369,11 +379,13 @@ def _too_many(R):
 
 
 def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, needs_grad, out_color=None, rows=None,
-                  radii_out=None):
+                  radii_out=None, shs=None, cov3D_precomp=None):
     """One view's forward through the C-ABI (capacity policy, early notification, overflow repair).  `ctx` is any attribute holder: the
     autograd ctx of _RasterizeGaussians, or a plain namespace when a caller drives several views itself (render_api._RenderBatch).
-    Leaves on it: raster_settings, cap, family, extra_flags, rows, saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws) and,
-    inside defer_capacity_checks(), ws_box.  out_color: optional preallocated contiguous fp32 [3,H,W] the image is written into.
+    Leaves on it: raster_settings, cap, family, extra_flags, rows, saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws, sh, cov, campos)
+    (col / sca / rot / sh / cov / campos: None where the other form of the input was given) and, inside defer_capacity_checks(), ws_box.
+    shs [P, M, 3] (M <= 16, evaluated up to raster_settings.sh_degree towards raster_settings.campos) INSTEAD of colors_precomp;
+    cov3D_precomp [P, 6] INSTEAD of scales + rotations.  out_color: optional preallocated contiguous fp32 [3,H,W] the image is written into.
     rows (a _Rows): the five inputs are batch-wide packed arrays, this view is the row range rows.offsets[rows.index : rows.index + 2] of
     them (read on the DEVICE), radii_out the batch-wide int32 radii array.  -> (color, radii)"""
     rs = raster_settings
@@ -387,12 +399,24 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
     P = N if rows is None else rows.capacity  # Gaussians of the view, or their upper bound
     H, W = int(rs.image_height), int(rs.image_width)
     m3 = _prep(means3D, "means3D", (3,), dev)
-    col = _prep(colors_precomp, "colors_precomp", (3,), dev)
     opa = _prep(opacities, "opacities", None, dev).reshape(-1)
-    sca = _prep(scales, "scales", (3,), dev)
-    rot = _prep(rotations, "rotations", (4,), dev)
-    if not (col.shape[0] == opa.shape[0] == sca.shape[0] == rot.shape[0] == N):
+    col = sca = rot = sh = cov = campos = None
+    if shs is None:
+        col = _prep(colors_precomp, "colors_precomp", (3,), dev)
+    else:
+        sh = _prep(shs, "shs", None, dev)
+        deg = int(rs.sh_degree)
+        if sh.dim() != 3 or sh.shape[2] != 3 or sh.shape[1] > 16 or not 0 <= deg <= 3 or (deg + 1) ** 2 > sh.shape[1]:
+            raise RuntimeError("shs must have dimensions (num_points, M, 3) with (sh_degree + 1)^2 <= M <= 16 and sh_degree in 0..3")
+        campos = _cam(rs.campos, 3, dev)
+    if cov3D_precomp is None:
+        sca = _prep(scales, "scales", (3,), dev)
+        rot = _prep(rotations, "rotations", (4,), dev)
+    else:
+        cov = _prep(cov3D_precomp, "cov3D_precomp", (6,), dev)
+    if not all(t is None or t.shape[0] == N for t in (col, opa, sca, rot, sh, cov)):
         raise RuntimeError("all per-Gaussian inputs must have num_points rows")
+    appear = (sh, int(rs.sh_degree), campos, cov, None, None) if (sh is not None or cov is not None) else None
     view = _cam(rs.viewmatrix, 16, dev)
     proj = _cam(rs.projmatrix, 16, dev)
     bg = _cam(rs.bg, 3, dev)
@@ -445,7 +469,7 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
                 note = (slot, hdr, w32, seq)
                 if not st.get("big_bins", False):
                     flags |= _capi.GSR_FLAG_NO_LARGE_SORT
-            ext = _ext(rows, st.get("longest", 0))  # work order: longest lists first, relative to the longest list seen on this device
+            ext = _ext(rows, st.get("longest", 0), appear)  # work order: longest lists first, relative to the longest list seen on this device
             rc = lib.gsr_forward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier), float(rs.tanfovx),
                                     float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
                                     stream, hdr_ptr, seq, C.byref(ext))
@@ -477,8 +501,9 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
         dump = os.environ.get("GPSGS_DUMP_INPUTS")  # debugging aid: the inputs of the LAST forward entered, as an .npz (synchronises)
         if dump and rows is None:
             import numpy as _np
-            _np.savez(dump, means3D=m3.cpu().numpy(), colors=col.cpu().numpy(), opacities=opa.cpu().numpy(), scales=sca.cpu().numpy(),
-                      rotations=rot.cpu().numpy(), view=view.cpu().numpy(), proj=proj.cpu().numpy(), bg=bg.cpu().numpy(), W=W, H=H,
+            _np.savez(dump, means3D=m3.cpu().numpy(), opacities=opa.cpu().numpy(),
+                      **{k: v.cpu().numpy() for k, v in (("colors", col), ("scales", sca), ("rotations", rot), ("shs", sh), ("cov3D_precomp", cov)) if v is not None},
+                      view=view.cpu().numpy(), proj=proj.cpu().numpy(), bg=bg.cpu().numpy(), W=W, H=H,
                       tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy), scale_modifier=float(rs.scale_modifier), cap=cap, needs_grad=bool(needs_grad))
         while True:
             ws, nbytes, note = launch(cap)
@@ -533,7 +558,7 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
     ctx.rows = rows
     if box is not None:
         ctx.ws_box = box
-    ctx.saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws)
+    ctx.saved = (m3, col, opa, sca, rot, view, proj, bg, radii, ws, sh, cov, campos)
     return color, radii
 
 
@@ -541,10 +566,12 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
     """One view's backward through the C-ABI.  color_grad=False: the caller does not need dL/dcolours (GSR_FLAG_NO_COLOR_GRAD: the tile
     family leaves the colour sums out; the returned colour gradient is zeros / not meaningful).  saved: the tuple _forward_impl left in ctx.saved; arena: optional five preallocated
     gradient tensors (means3D, colours, opacities, scales, rotations) -- for a row-range view (ctx.rows) they are REQUIRED and batch-wide,
-    the view's rows of them are written.  -> (d_m3, d_m2, d_col, d_op, d_sc, d_rot)"""
+    the view's rows of them are written.  -> (d_m3, d_m2, d_col, d_op, d_sc, d_rot, d_sh, d_cov); d_sh / d_cov are None unless the forward was given
+    SH coefficients / precomputed covariances (d_sc, d_rot are then not meaningful)."""
     rs = ctx.raster_settings
     lib = _capi.lib()
-    m3, col, opa, sca, rot, view, proj, bg, radii, ws = saved
+    m3, col, opa, sca, rot, view, proj, bg, radii, ws = saved[:10]
+    sh, cov, campos = saved[10:13] if len(saved) >= 13 else (None, None, None)
     cap = ctx.cap
     rows = getattr(ctx, "rows", None)
     box = getattr(ctx, "ws_box", None)
@@ -576,15 +603,17 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
             b_rot, b_m3, b_m2, b_col, b_sc, b_op = buf.split_with_sizes((4 * P, 3 * P, 3 * P, 3 * P, 3 * P, P))
             d_rot, d_m3, d_m2 = b_rot.view(P, 4), b_m3.view(P, 3), b_m2.view(P, 3)
             d_col, d_sc, d_op = b_col.view(P, 3), b_sc.view(P, 3), b_op.view(P, 1)
+        d_sh = torch.empty_like(sh) if sh is not None else None
+        d_cov = torch.empty_like(cov) if cov is not None else None
         if P > 0:
-            ext = _ext(rows, 0)
+            ext = _ext(rows, 0, (sh, int(rs.sh_degree), campos, cov, d_sh, d_cov) if (sh is not None or cov is not None) else None)
             rc = lib.gsr_backward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
                                      _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
                                      ws.numel(), cap, (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | getattr(ctx, "extra_flags", _extra_flags) | ctx.family
                                      | (0 if color_grad else _capi.GSR_FLAG_NO_COLOR_GRAD), stream, C.byref(ext))
             _capi.check(rc, "gsr_backward_ex")
-    return d_m3, d_m2, d_col, d_op, d_sc, d_rot
+    return d_m3, d_m2, d_col, d_op, d_sc, d_rot, d_sh, d_cov
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -595,8 +624,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         # fresh allocations, so that the batch's gradients arrive already concatenated (render_api._SplitRows)
         ctx.grad_arena = grad_arena
         # stage 2 never differentiates the colours (they are input pixels, lib/GaussianRender.py:30-31): the backward then skips their sums
-        ctx.color_grad = bool(ctx.needs_input_grad[3])
-        color, radii = _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, any(ctx.needs_input_grad))
+        ctx.color_grad = bool(ctx.needs_input_grad[3]) or sh is not None  # (dL/dsh is formed from dL/dcolour)
+        color, radii = _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, any(ctx.needs_input_grad),
+                                     shs=sh, cov3D_precomp=cov3Ds_precomp)
         ctx.save_for_backward(*ctx.saved)
         ctx.saved = None
         ctx.mark_non_differentiable(radii)
@@ -607,9 +637,12 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         if grad_out_color is None:  # the image did not take part in the loss
             return (None,) * 10
-        d_m3, d_m2, d_col, d_op, d_sc, d_rot = _backward_impl(ctx, ctx.saved_tensors, grad_out_color, ctx.grad_arena, ctx.color_grad)
+        saved = ctx.saved_tensors
+        d_m3, d_m2, d_col, d_op, d_sc, d_rot, d_sh, d_cov = _backward_impl(ctx, saved, grad_out_color, ctx.grad_arena, ctx.color_grad)
+        has_sh, has_cov = saved[10] is not None, saved[11] is not None
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
-        return d_m3, d_m2, None, (d_col if ctx.color_grad else None), d_op, d_sc, d_rot, None, None, None
+        return (d_m3, d_m2, d_sh, (d_col if ctx.color_grad and not has_sh else None), d_op, (None if has_cov else d_sc), (None if has_cov else d_rot),
+                d_cov, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, grad_arena=None):
@@ -632,15 +665,10 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        if shs is not None:
-            raise NotImplementedError(
-                "gps_gaussian_amd: spherical-harmonics colours are outside the GPS-Gaussian hot path (the reference always "
-                "passes colors_precomp, gaussian_renderer/__init__.py:54-62)")
-        if cov3D_precomp is not None:
-            raise NotImplementedError(
-                "gps_gaussian_amd: precomputed 3D covariances are outside the GPS-Gaussian hot path (the reference always "
-                "passes scales+rotations, gaussian_renderer/__init__.py:54-62)")
-        return rasterize_gaussians(means3D, means2D, None, colors_precomp, opacities, scales, rotations, None,
+        # shs [P, M, 3] are evaluated up to raster_settings.sh_degree towards raster_settings.campos (upstream computeColorFromSH); cov3D_precomp
+        # [P, 6] replaces scale + rotation.  The reference passes neither (gaussian_renderer/__init__.py:54-62) but constructs the settings
+        # with sh_degree = 3 and campos (:46-47): both inputs are part of the module it imports.
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings, grad_arena)
 
 

@@ -275,3 +275,25 @@ def make_clamp_cloud(n_gauss, W, H, seed=SEED, z_range=(0.5, 4.0), scale_med=0.0
         view=wvt, proj=(wvt @ proj).astype(np.float32), campos=campos, W=W, H=H,
         tanfovx=W / (2 * fx), tanfovy=H / (2 * fx), bg=np.array([0.3, 0.1, 0.2], np.float32),
     )
+
+
+def random_shs(n_gauss, coeffs=16, seed=SEED, dc_spread=1.2, band_sigma=0.35):
+    """Random spherical-harmonics coefficients [n, coeffs, 3]: a DC term that puts most colours into (0, 1) and a minority below zero (so that
+    the `max(colour, 0)` clamp of the SH path and its cut gradient are exercised), higher bands at `band_sigma`."""
+    rng = np.random.default_rng(seed + 7919)
+    sh = rng.normal(0.0, band_sigma, (n_gauss, coeffs, 3))
+    sh[:, 0, :] = rng.uniform(-0.5 - dc_spread, 0.5 + dc_spread, (n_gauss, 3)) / 0.28209479177387814 * 0.5
+    return sh.astype(np.float32)
+
+
+def covariances_from(scales, rotations, scale_modifier=1.0):
+    """[n, 6] upper triangles (xx, xy, xz, yy, yz, zz) of R diag(s)^2 R^T, the layout of `cov3D_precomp` (quaternions (w, x, y, z), used
+    un-normalised like the rasteriser does)."""
+    q = np.asarray(rotations, np.float64)
+    s = np.asarray(scales, np.float64) * scale_modifier
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)], 1),
+                  np.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)], 1),
+                  np.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1)], 1)
+    S = np.einsum("nij,nj,nkj->nik", R, s * s, R)
+    return np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)

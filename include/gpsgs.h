@@ -12,7 +12,9 @@
  *       the `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` calls made by the external CUDA
  *       extension `diff_gaussian_rasterization`, which the reference imports at gaussian_renderer/__init__.py:14
  *       and invokes at gaussian_renderer/__init__.py:51-62 (GaussianRasterizer.forward) and, through autograd,
- *       from train_stage2.py:83 (backward).  Argument meaning follows that call: precomputed colours, no SH.
+ *       from train_stage2.py:83 (backward).  Argument meaning follows that call: precomputed colours, scale + rotation.  The other
+ *       half of that module's interface -- `shs` (settings fields sh_degree / campos, constructed at gaussian_renderer/__init__.py:46-47)
+ *       and `cov3D_precomp`, both passed as None by the reference (:56,:61) -- travels in GsrViewExt.
  *   cs_forward / cs_backward
  *       `corr_sampler.forward` / `corr_sampler.backward` of the external RAFT-Stereo sampler extension, called at
  *       core/corr.py:22 and core/corr.py:28.
@@ -38,7 +40,9 @@
 extern "C" {
 #endif
 
-#define GPSGS_ABI_VERSION 2 /* 2: + GsrViewExt, gsr_forward_ex, gsr_backward_ex; header words num_points / row_overflow (additive) */
+#define GPSGS_ABI_VERSION 3 /* 2: + GsrViewExt, gsr_forward_ex, gsr_backward_ex; header words num_points / row_overflow (additive)
+                               3: GsrViewExt grew from 32 to 80 bytes: SH colours and precomputed 3D covariances (the `shs` / `cov3D_precomp`
+                                  inputs of the upstream module, + their gradients); zero-initialised it means what version 2 meant */
 
 enum {
     GPSGS_OK = 0,
@@ -151,7 +155,26 @@ int gsr_forward_notify(int P, int width, int height, const float *means3D, const
 typedef struct GsrViewExt {
     const uint32_t *row_range;
     uint32_t order_hint;
-    uint32_t reserved[5];
+    /* ---- ABI 3: appearance / covariance inputs the reference never passes but its rasteriser module accepts ---------------------------
+     *   shs            DEVICE [rows, sh_coeffs, 3] real spherical-harmonics coefficients (sh_coeffs <= 16), evaluated up to degree
+     *                  sh_degree (0..3, (sh_degree + 1)^2 <= sh_coeffs) in the direction campos -> mean, + 0.5, clamped at 0 (upstream
+     *                  computeColorFromSH).  With shs the `colors` argument of the call must be NULL (exactly one of the two), campos
+     *                  (DEVICE [3], the settings' camera centre) is required, and the backward writes dL_dsh [rows, sh_coeffs, 3]
+     *                  (zeros beyond the active degree and for invisible Gaussians) and adds the view-direction term to dL_dmeans3D;
+     *                  its dL_dcolors argument may then be NULL.
+     *   cov3D_precomp  DEVICE [rows, 6] upper triangles (xx, xy, xz, yy, yz, zz), used as given (scale_modifier does not apply).  With it
+     *                  `scales` and `rotations` must be NULL (exactly one of the two forms); the backward writes dL_dcov3D [rows, 6]
+     *                  (upstream's convention: an off-diagonal entry carries both symmetric positions) and leaves dL_dscales / dL_drotations
+     *                  untouched (they may be NULL). */
+    uint32_t sh_degree;
+    uint32_t sh_coeffs;
+    uint32_t reserved0;
+    const float *shs;
+    const float *campos;
+    const float *cov3D_precomp;
+    float *dL_dsh;      /* gsr_backward_ex only */
+    float *dL_dcov3D;   /* gsr_backward_ex only */
+    uint32_t reserved[4];
 } GsrViewExt;
 
 /* gsr_forward_notify + GsrViewExt (host_header_out may be NULL: no notification, like gsr_forward).  The early header's word 6 carries

@@ -74,17 +74,23 @@ class OracleRasterizer:
         return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
     def forward(self, means3D, colors, opacities, scales, rotations, view, proj, W, H, tanfovx, tanfovy, bg,
-                scale_modifier=1.0, decisions=None):
+                scale_modifier=1.0, decisions=None, shs=None, sh_degree=0, campos=None, cov3D_precomp=None):
         """view/proj: the [4,4] tensors exactly as the reference hands them over (transposed; flat = column-major).
         decisions: optional geom() dict of ANOTHER evaluation (normally the fp32 oracle) whose discrete decisions
         (radii/visibility, tile rect, fp32 depth sort key) are adopted; see gsr_oracle.c.
+        The other half of the upstream interface: shs [P,M,3] (+ sh_degree 0..3, campos [3]) INSTEAD of colors (pass colors=None),
+        cov3D_precomp [P,6] INSTEAD of scales + rotations (pass both None).
         Returns (color[3,H,W], radii[P])."""
         P = int(np.asarray(means3D).reshape(-1, 3).shape[0])
         a = dict(
-            means3D=self._a(means3D, (P, 3)), colors=self._a(colors, (P, 3)), opacities=self._a(opacities, (P,)),
-            scales=self._a(scales, (P, 3)), rotations=self._a(rotations, (P, 4)),
+            means3D=self._a(means3D, (P, 3)), colors=None if colors is None else self._a(colors, (P, 3)), opacities=self._a(opacities, (P,)),
+            scales=None if scales is None else self._a(scales, (P, 3)), rotations=None if rotations is None else self._a(rotations, (P, 4)),
             view=self._a(view, (16,)), proj=self._a(proj, (16,)), bg=self._a(bg, (3,)),
+            shs=None if shs is None else self._a(shs, (P, -1, 3)), campos=None if campos is None else self._a(campos, (3,)),
+            cov3D_precomp=None if cov3D_precomp is None else self._a(cov3D_precomp, (P, 6)),
         )
+        M = 0 if a["shs"] is None else int(a["shs"].shape[1])
+        self.sh = (int(sh_degree), M)
         self.args = (P, a, float(scale_modifier), int(W), int(H), float(tanfovx), float(tanfovy))
         out = np.zeros((3, H, W), self.np)
         radii = np.zeros((max(P, 1),), np.int32)
@@ -93,36 +99,53 @@ class OracleRasterizer:
             ov = (np.ascontiguousarray(decisions["radii"], np.int32), np.ascontiguousarray(decisions["rect"], np.int32),
                   np.ascontiguousarray(decisions["depth"], np.float32))
         self._ov = ov
-        rc = self._f("forward")(
+        rc = self._f("forward_ex")(
             self.h, C.c_int(P), self._p(a["means3D"]), self._p(a["colors"]), self._p(a["opacities"]),
             self._p(a["scales"]), self._p(a["rotations"]), self.ct(scale_modifier), self._p(a["view"]),
             self._p(a["proj"]), C.c_int(W), C.c_int(H), self.ct(tanfovx), self.ct(tanfovy), self._p(a["bg"]),
-            self._p(out), self._p(radii), self._p(ov[0]), self._p(ov[1]), self._p(ov[2]))
+            self._p(out), self._p(radii), self._p(ov[0]), self._p(ov[1]), self._p(ov[2]),
+            self._p(a["shs"]), C.c_int(self.sh[0]), C.c_int(M), self._p(a["campos"]), self._p(a["cov3D_precomp"]))
         if rc != 0:
             raise RuntimeError("oracle forward failed rc=%d" % rc)
         return out, radii[:P]
 
     def backward(self, dL_dpix, debug=False):
+        """-> dict of gradients: means3D, means2D, colors (dL/d of the blended colour, also with SH inputs), opacities, scales, rotations;
+        with SH inputs also shs [P,M,3], with cov3D_precomp also cov3D_precomp [P,6] (scales / rotations then stay zero)."""
         P, a, mod, W, H, tx, ty = self.args
         g = self._a(dL_dpix, (3, H, W))
         n = max(P, 1)
+        deg, M = self.sh
         o = dict(means3D=np.zeros((n, 3), self.np), means2D=np.zeros((n, 3), self.np), colors=np.zeros((n, 3), self.np),
                  opacities=np.zeros((n, 1), self.np), scales=np.zeros((n, 3), self.np), rotations=np.zeros((n, 4), self.np))
         dconic = np.zeros((n, 3), self.np) if debug else None
-        dcov = np.zeros((n, 6), self.np) if debug else None
-        rc = self._f("backward")(
+        dcov = np.zeros((n, 6), self.np) if (debug or a["cov3D_precomp"] is not None) else None
+        dsh = np.zeros((n, M, 3), self.np) if a["shs"] is not None else None
+        rc = self._f("backward_ex")(
             self.h, C.c_int(P), self._p(a["means3D"]), self._p(a["colors"]), self._p(a["opacities"]),
             self._p(a["scales"]), self._p(a["rotations"]), self.ct(mod), self._p(a["view"]), self._p(a["proj"]),
             C.c_int(W), C.c_int(H), self.ct(tx), self.ct(ty), self._p(a["bg"]), self._p(g),
             self._p(o["means3D"]), self._p(o["means2D"]), self._p(o["colors"]), self._p(o["opacities"]),
-            self._p(o["scales"]), self._p(o["rotations"]), self._p(dconic), self._p(dcov))
+            self._p(o["scales"]), self._p(o["rotations"]), self._p(dconic), self._p(dcov),
+            self._p(a["shs"]), C.c_int(deg), C.c_int(M), self._p(a["campos"]), self._p(a["cov3D_precomp"]), self._p(dsh))
         if rc != 0:
             raise RuntimeError("oracle backward failed rc=%d" % rc)
         o = {k: v[:P] for k, v in o.items()}
         if debug:
             o["conic"] = dconic[:P]
             o["cov3D"] = dcov[:P]
+        if a["shs"] is not None:
+            o["shs"] = dsh[:P]
+        if a["cov3D_precomp"] is not None:
+            o["cov3D_precomp"] = dcov[:P]
         return o
+
+    def rgb(self):
+        """[P,3] colours that were blended (precomputed, or evaluated from the SH coefficients); zeros for invisible Gaussians."""
+        P = self.args[0]
+        out = np.zeros((max(P, 1), 3), self.np)
+        self._f("export_rgb")(self.h, self._p(out))
+        return out[:P]
 
     @property
     def num_rendered(self):

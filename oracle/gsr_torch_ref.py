@@ -41,10 +41,40 @@ def _xf(m, p, rows):
     return torch.stack([m[r] * p[:, 0] + m[4 + r] * p[:, 1] + m[8 + r] * p[:, 2] + m[12 + r] for r in range(rows)], 1)
 
 
+_SH_C0 = 0.28209479177387814
+_SH_C1 = 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+          -0.5900435899266435)
+
+
+def sh_to_rgb(shs, degree, means3D, campos):
+    """Colour of every Gaussian from its real spherical-harmonics coefficients shs [P,M,3] evaluated in the direction camera -> Gaussian
+    (the published basis of the 3D-Gaussian-splatting rasteriser: constants above), + 0.5, clamped at 0.  Plain torch ops: autograd
+    differentiates the clamp (zero where the sum is negative), the basis and the normalisation of the direction."""
+    d = means3D - campos[None, :]
+    d = d / d.norm(dim=1, keepdim=True)
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    c = _SH_C0 * shs[:, 0]
+    if degree > 0:
+        c = c - _SH_C1 * y * shs[:, 1] + _SH_C1 * z * shs[:, 2] - _SH_C1 * x * shs[:, 3]
+    if degree > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        c = (c + _SH_C2[0] * xy * shs[:, 4] + _SH_C2[1] * yz * shs[:, 5] + _SH_C2[2] * (2 * zz - xx - yy) * shs[:, 6]
+             + _SH_C2[3] * xz * shs[:, 7] + _SH_C2[4] * (xx - yy) * shs[:, 8])
+    if degree > 2:
+        c = (c + _SH_C3[0] * y * (3 * xx - yy) * shs[:, 9] + _SH_C3[1] * xy * z * shs[:, 10] + _SH_C3[2] * y * (4 * zz - xx - yy) * shs[:, 11]
+             + _SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * shs[:, 12] + _SH_C3[4] * x * (4 * zz - xx - yy) * shs[:, 13]
+             + _SH_C3[5] * z * (xx - yy) * shs[:, 14] + _SH_C3[6] * x * (xx - 3 * yy) * shs[:, 15])
+    c = c + 0.5
+    return torch.where(c < 0, torch.zeros_like(c), c)
+
+
 def render_ref(means3D, colors, opacities, scales, rotations, view, proj, W, H, tanfovx, tanfovy, bg,
-               scale_modifier=1.0, ndc_offset=None):
+               scale_modifier=1.0, ndc_offset=None, shs=None, sh_degree=0, campos=None, cov3D_precomp=None):
     """All tensor inputs fp64.  Returns (image[3,H,W], radii[P]).  ndc_offset: optional zeros[P,2] leaf whose
-    gradient is the upstream `dL_dmeans2D[:, :2]`."""
+    gradient is the upstream `dL_dmeans2D[:, :2]`.  shs [P,M,3] + sh_degree + campos replace `colors` (None), cov3D_precomp [P,6]
+    (xx, xy, xz, yy, yz, zz) replaces scales + rotations (None)."""
     dt = torch.float64
     P = means3D.shape[0]
     view = view.reshape(16).to(dt)
@@ -63,13 +93,20 @@ def render_ref(means3D, colors, opacities, scales, rotations, view, proj, W, H, 
     if ndc_offset is not None:
         ndc = ndc + ndc_offset
 
-    r, x, y, z = rotations.unbind(1)
-    Rm = torch.stack([
-        torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)], 1),
-        torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)], 1),
-        torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1)], 1)  # [P,3,3]
-    S2 = torch.diag_embed((scale_modifier * scales) ** 2)
-    Sigma = Rm @ S2 @ Rm.transpose(1, 2)
+    if shs is not None:
+        colors = sh_to_rgb(shs, sh_degree, means3D, campos.to(dt))
+    if cov3D_precomp is not None:
+        c6 = cov3D_precomp
+        Sigma = torch.stack([torch.stack([c6[:, 0], c6[:, 1], c6[:, 2]], 1), torch.stack([c6[:, 1], c6[:, 3], c6[:, 4]], 1),
+                             torch.stack([c6[:, 2], c6[:, 4], c6[:, 5]], 1)], 1)
+    else:
+        r, x, y, z = rotations.unbind(1)
+        Rm = torch.stack([
+            torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)], 1),
+            torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)], 1),
+            torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1)], 1)  # [P,3,3]
+        S2 = torch.diag_embed((scale_modifier * scales) ** 2)
+        Sigma = Rm @ S2 @ Rm.transpose(1, 2)
 
     tz = p_view[:, 2]
     limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
@@ -133,28 +170,33 @@ def render_ref(means3D, colors, opacities, scales, rotations, view, proj, W, H, 
     return out.t().reshape(3, H, W), radii
 
 
-def grads_ref(inputs, W, H, tanfovx, tanfovy, dL_dpix, scale_modifier=1.0):
-    """inputs: dict of numpy/tensors (means3D, colors, opacities[P,1], scales, rotations, view, proj, bg).
+def grads_ref(inputs, W, H, tanfovx, tanfovy, dL_dpix, scale_modifier=1.0, sh_degree=None):
+    """inputs: dict of numpy/tensors (means3D, colors, opacities[P,1], scales, rotations, view, proj, bg; optionally shs [P,M,3] +
+    campos -- used instead of colors when sh_degree is given -- and cov3D_precomp [P,6], used instead of scales + rotations).
     Returns (image, radii, dict of gradients named like the oracle's)."""
     dt = torch.float64
+    use_sh = sh_degree is not None
+    use_cov = inputs.get("cov3D_precomp") is not None
     t = {k: torch.as_tensor(v).to(dt).clone() for k, v in inputs.items() if k in
-         ("means3D", "colors", "opacities", "scales", "rotations", "view", "proj", "bg")}
+         ("means3D", "colors", "opacities", "scales", "rotations", "view", "proj", "bg", "shs", "campos", "cov3D_precomp") and v is not None}
     t["opacities"] = t["opacities"].reshape(-1)
-    leaves = ["means3D", "colors", "opacities", "scales", "rotations"]
+    leaves = ["means3D", "shs" if use_sh else "colors", "opacities"] + (["cov3D_precomp"] if use_cov else ["scales", "rotations"])
     for k in leaves:
         t[k].requires_grad_(True)
     off = torch.zeros(t["means3D"].shape[0], 2, dtype=dt, requires_grad=True)
-    img, radii = render_ref(t["means3D"], t["colors"], t["opacities"], t["scales"], t["rotations"], t["view"],
-                            t["proj"], W, H, tanfovx, tanfovy, t["bg"], scale_modifier, off)
+    img, radii = render_ref(t["means3D"], None if use_sh else t["colors"], t["opacities"], None if use_cov else t["scales"],
+                            None if use_cov else t["rotations"], t["view"], t["proj"], W, H, tanfovx, tanfovy, t["bg"], scale_modifier, off,
+                            shs=t["shs"] if use_sh else None, sh_degree=sh_degree or 0, campos=t.get("campos"),
+                            cov3D_precomp=t["cov3D_precomp"] if use_cov else None)
     loss = (img * torch.as_tensor(dL_dpix).to(dt)).sum()
     if loss.requires_grad:
         gs = torch.autograd.grad(loss, [t[k] for k in leaves] + [off], allow_unused=True)
     else:
-        gs = [None] * 6
+        gs = [None] * (len(leaves) + 1)
     out = {}
-    for k, g in zip(leaves, gs[:5]):
+    for k, g in zip(leaves, gs[:-1]):
         out[k] = (torch.zeros_like(t[k]) if g is None else g).detach().numpy()
     out["opacities"] = out["opacities"].reshape(-1, 1)
-    g2 = torch.zeros_like(off) if gs[5] is None else gs[5]
+    g2 = torch.zeros_like(off) if gs[-1] is None else gs[-1]
     out["means2D"] = torch.cat([g2, torch.zeros(g2.shape[0], 1, dtype=dt)], 1).detach().numpy()
     return img.detach().numpy(), radii.numpy(), out

@@ -49,28 +49,40 @@ def oracle_render(scene, kind="f32", decisions=None):
     return o, img, radii
 
 
-def hip_render(scene, dpix=None, debug=False):
-    """Runs the HIP rasteriser through the drop-in module (C-ABI underneath). Returns (img, radii, grads|None, info|None) with info = dict(ws=workspace tensor, cap=instance capacity)."""
+def hip_render(scene, dpix=None, debug=False, shs=None, sh_degree=3, cov3D_precomp=None):
+    """Runs the HIP rasteriser through the drop-in module (C-ABI underneath). Returns (img, radii, grads|None, info|None) with info = dict(ws=workspace tensor, cap=instance capacity).
+    shs [P,M,3] (+ sh_degree): SH colours INSTEAD of scene["colors"]; cov3D_precomp [P,6]: INSTEAD of scales + rotations (the gradient dict then
+    carries "shs" / "cov3D_precomp" in place of "colors" / "scales" + "rotations")."""
     import torch
     import gps_gaussian_amd  # noqa: F401
     from gps_gaussian_amd import rasterizer as RZ
 
     dev = torch.device("cuda:0")
-    names = ("means3D", "colors", "opacities", "scales", "rotations")
-    t = {k: torch.from_numpy(np.ascontiguousarray(scene[k], dtype=np.float32)).to(dev).requires_grad_(dpix is not None) for k in names}
+    src = dict(scene)
+    names = ["means3D", "opacities"]
+    if shs is None:
+        names.append("colors")
+    else:
+        names.append("shs"); src["shs"] = shs
+    if cov3D_precomp is None:
+        names += ["scales", "rotations"]
+    else:
+        names.append("cov3D_precomp"); src["cov3D_precomp"] = cov3D_precomp
+    t = {k: torch.from_numpy(np.ascontiguousarray(src[k], dtype=np.float32)).to(dev).requires_grad_(dpix is not None) for k in names}
     m2 = torch.zeros_like(t["means3D"], requires_grad=dpix is not None)
     rs = RZ.GaussianRasterizationSettings(
         image_height=scene["H"], image_width=scene["W"], tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"],
         bg=torch.from_numpy(scene["bg"]).to(dev), scale_modifier=float(scene.get("scale_modifier", 1.0)), viewmatrix=torch.from_numpy(scene["view"]).to(dev),
-        projmatrix=torch.from_numpy(scene["proj"]).to(dev), sh_degree=3, campos=torch.from_numpy(scene["campos"]).to(dev),
+        projmatrix=torch.from_numpy(scene["proj"]).to(dev), sh_degree=sh_degree, campos=torch.from_numpy(scene["campos"]).to(dev),
         prefiltered=False, debug=debug)
-    img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=None, colors_precomp=t["colors"],
-                                           opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=t.get("shs"), colors_precomp=t.get("colors"),
+                                           opacities=t["opacities"], scales=t.get("scales"), rotations=t.get("rotations"),
+                                           cov3D_precomp=t.get("cov3D_precomp"))
     grads = None
     info = None
     if dpix is not None:
         fn = img.grad_fn  # grab the forward's workspace before backward frees the saved tensors
-        ws = [x for x in fn.saved_tensors if x.dtype == torch.uint8][0]
+        ws = [x for x in fn.saved_tensors if x is not None and x.dtype == torch.uint8][0]
         info = dict(ws=ws, cap=fn.cap)
         img.backward(torch.from_numpy(np.ascontiguousarray(dpix, dtype=np.float32)).to(dev))
         grads = {k: t[k].grad.cpu().numpy() for k in names}

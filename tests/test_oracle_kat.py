@@ -102,3 +102,94 @@ def test_decisions_override_is_idempotent():
     assert (radii == radii2).all()
     np.testing.assert_array_equal(img, img2)
     np.testing.assert_array_equal(o.binning()["point_list"], o2.binning()["point_list"])
+
+
+# ---- the other half of the upstream interface: SH colours and precomputed 3D covariances -------------------------------
+def _oracle_ex(g, kind, shs=None, degree=0, cov=None, decisions=None):
+    o = OracleRasterizer(kind)
+    img, radii = o.forward(g["means3D"], None if shs is not None else g["colors"], g["opacities"], None if cov is not None else g["scales"],
+                           None if cov is not None else g["rotations"], g["view"], g["proj"], g["W"], g["H"], g["tanfovx"], g["tanfovy"], g["bg"],
+                           scale_modifier=float(g.get("scale_modifier", 1.0)), decisions=decisions, shs=shs, sh_degree=degree, campos=g["campos"],
+                           cov3D_precomp=cov)
+    return o, img, radii
+
+
+@pytest.mark.parametrize("degree,coeffs", [(0, 1), (1, 4), (2, 9), (3, 16), (1, 16), (0, 16)])
+def test_sh_colours_backward_matches_independent_autograd(degree, coeffs):
+    """dL/dsh and the view-direction term of dL/dmeans3D (hand-derived in the C oracle) equal torch.autograd through the published SH basis;
+    coefficients beyond the active degree get exact zeros; a share of the colour channels sits on the max(., 0) clamp."""
+    W, H, n = 48, 40, 260
+    g = S.make_clamp_cloud(n, W, H, seed=20 + degree, scale_med=0.06, spread=0.1, opacity_logit=(0.0, 1.5))  # rotated + translated camera: campos != 0
+    shs = S.random_shs(n, coeffs, seed=degree)
+    dpix = np.random.default_rng(degree).standard_normal((3, H, W))
+    o, img, radii = _oracle_ex(g, "f64", shs=shs, degree=degree)
+    gr = o.backward(dpix)
+    img2, radii2, gr2 = grads_ref(dict(g, shs=shs), W, H, g["tanfovx"], g["tanfovy"], dpix, sh_degree=degree)
+    vis = radii > 0
+    rgb = o.rgb()
+    clamped = (rgb[vis] == 0.0).mean()
+    print("visible %d of %d, colour channels on the clamp: %.1f %%" % (vis.sum(), n, 100 * clamped))
+    assert (radii == radii2).all() and vis.sum() > n // 4 and 0.03 < clamped < 0.6
+    np.testing.assert_allclose(img, img2, atol=1e-12)
+    nb = (degree + 1) ** 2
+    assert np.abs(gr["shs"][:, nb:]).max(initial=0.0) == 0.0 and np.abs(gr["shs"][~vis]).max(initial=0.0) == 0.0
+    assert np.abs(gr["shs"][:, :nb]).max() > 0
+    for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
+
+
+def test_sh_degree_0_equals_precomputed_colours():
+    """Degree 0 is direction-free: the image and every shared gradient equal those of colors_precomp = max(C0 sh0 + 0.5, 0), bit for bit."""
+    W, H, n = 64, 48, 500
+    g = S.make_uniform_cloud(n, W, H, seed=31, scale_med=0.05)
+    g["campos"] = np.array([0.3, -0.2, -0.5], np.float32)
+    shs = S.random_shs(n, 16, seed=3)
+    o, img, radii = _oracle_ex(g, "f32", shs=shs, degree=0)
+    col = o.rgb().copy()
+    # invisible Gaussians have no evaluated colour; give them anything
+    o2 = OracleRasterizer("f32")
+    img2, radii2 = o2.forward(g["means3D"], col, g["opacities"], g["scales"], g["rotations"], g["view"], g["proj"], W, H, g["tanfovx"], g["tanfovy"], g["bg"])
+    np.testing.assert_array_equal(img, img2)
+    dpix = np.random.default_rng(5).standard_normal((3, H, W)).astype(np.float32)
+    a, b = o.backward(dpix), o2.backward(dpix)
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations", "colors"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    want = np.float32(0.28209479177387814) * (b["colors"] * (col > 0))
+    np.testing.assert_allclose(a["shs"][:, 0], want, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed,mod", [(41, 1.0), (42, 0.7)])
+def test_precomputed_covariance_backward_matches_independent_autograd(seed, mod):
+    """cov3D_precomp replaces scale + rotation: same image as the scale/rotation form of the same covariances (fp64: to rounding), and
+    dL/dcov3D (upstream's 6-vector: off-diagonals carry both symmetric positions) equals autograd through a symmetric matrix built from it."""
+    W, H, n = 56, 44, 300
+    g = S.make_clamp_cloud(n, W, H, seed=seed, scale_med=0.07, spread=0.3)
+    g["scale_modifier"] = mod
+    cov = S.covariances_from(g["scales"], g["rotations"], mod).astype(np.float64)
+    dpix = np.random.default_rng(seed).standard_normal((3, H, W))
+    o, img, radii = _oracle_ex(g, "f64", cov=cov)
+    gr = o.backward(dpix)
+    o0, img0, radii0 = oracle_render(g, "f64")
+    assert (radii == radii0).all() and (radii > 0).sum() > n // 5
+    np.testing.assert_allclose(img, img0, atol=1e-6)  # cov was rounded to fp32 by the helper
+    img2, radii2, gr2 = grads_ref(dict(g, cov3D_precomp=cov), W, H, g["tanfovx"], g["tanfovy"], dpix, scale_modifier=mod)
+    assert (radii == radii2).all()
+    np.testing.assert_allclose(img, img2, atol=1e-12)
+    assert np.abs(gr["scales"]).max() == 0.0 and np.abs(gr["rotations"]).max() == 0.0
+    for k in ("means3D", "means2D", "colors", "opacities", "cov3D_precomp"):
+        np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
+
+
+def test_sh_and_precomputed_covariance_together():
+    W, H, n = 40, 40, 200
+    g = S.make_clamp_cloud(n, W, H, seed=51, scale_med=0.08, spread=0.2)
+    cov = S.covariances_from(g["scales"], g["rotations"]).astype(np.float64)
+    shs = S.random_shs(n, 16, seed=9)
+    dpix = np.random.default_rng(9).standard_normal((3, H, W))
+    o, img, radii = _oracle_ex(g, "f64", shs=shs, degree=3, cov=cov)
+    gr = o.backward(dpix)
+    img2, radii2, gr2 = grads_ref(dict(g, shs=shs, cov3D_precomp=cov), W, H, g["tanfovx"], g["tanfovy"], dpix, sh_degree=3)
+    assert (radii == radii2).all()
+    np.testing.assert_allclose(img, img2, atol=1e-12)
+    for k in ("means3D", "means2D", "shs", "opacities", "cov3D_precomp"):
+        np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
