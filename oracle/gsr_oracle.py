@@ -179,3 +179,29 @@ class OracleRasterizer:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
         f(self.h, self._p(m), float(power_band))
         return m
+
+    def flip_bound(self, dL_dpix, thresh=1e-5, power_band=1e-6):
+        """-> (touched [P] bool, bounds dict shaped like backward()'s gradients).  touched[g]: Gaussian g takes part (alpha >= 1/255 with 1 % slack, inside
+        its tile rect, in front of a clear stop) in a pixel that sits within `thresh` of a branch threshold; bounds[k][g]: upper bound on the magnitude
+        of the part of g's gradient k that comes from those pixels -- what a flipped branch decision there can change (gsr_oracle.c flip_bound)."""
+        P, a, mod, W, H, tx, ty = self.args
+        g = self._a(dL_dpix, (3, H, W))
+        margin = self.fragility(power_band)
+        n = max(P, 1)
+        deg, M = self.sh
+        touched = np.zeros(n, np.uint8)
+        use_cov, use_sh = a["cov3D_precomp"] is not None, a["shs"] is not None
+        b = dict(means3D=np.zeros((n, 3), self.np), means2D=np.zeros((n, 3), self.np), colors=np.zeros((n, 3), self.np), opacities=np.zeros((n, 1), self.np),
+                 scales=None if use_cov else np.zeros((n, 3), self.np), rotations=None if use_cov else np.zeros((n, 4), self.np),
+                 cov3D_precomp=np.zeros((n, 6), self.np) if use_cov else None, shs=np.zeros((n, M, 3), self.np) if use_sh else None)
+        f = self._f("flip_bound")
+        rc = f(self.h, C.c_int(P), self._p(a["means3D"]), self._p(a["opacities"]), self._p(a["scales"]), self._p(a["rotations"]), self.ct(mod),
+               self._p(a["view"]), self._p(a["proj"]), C.c_int(W), C.c_int(H), self.ct(tx), self.ct(ty), self._p(a["bg"]), self._p(g),
+               self._p(a["shs"]), C.c_int(deg), C.c_int(M), self._p(a["campos"]), self._p(a["cov3D_precomp"]),
+               self._p(margin), self.ct(thresh), C.c_double(power_band), touched.ctypes.data_as(C.c_void_p),
+               self._p(b["means3D"]), self._p(b["means2D"]), self._p(b["colors"]), self._p(b["opacities"]), self._p(b["scales"]), self._p(b["rotations"]),
+               self._p(b["cov3D_precomp"]), self._p(b["shs"]))
+        if rc != 0:
+            raise RuntimeError("oracle flip_bound failed rc=%d" % rc)
+        return touched[:P].astype(bool), {k: v[:P] for k, v in b.items() if v is not None}
+

@@ -5,7 +5,7 @@ settings with sh_degree = 3 and campos (:46-47); BASELINE config 5 names "SH deg
 import numpy as np
 import pytest
 
-from conftest import assert_grad_parity, hip_render, parity_report, touched_by_fragile
+from conftest import assert_grad_parity, fragile_bounds, hip_render, parity_report
 from test_gpu_raster import _assert_full_size_grads, family  # noqa: F401  (fixture: both compositing kernel families)
 
 pytestmark = pytest.mark.gpu
@@ -24,16 +24,16 @@ def _oracle(g, kind="f32", shs=None, degree=0, cov=None):
 
 def _check(name, g, dpix, img, radii, grads, o, oimg, oradii, rename):
     np.testing.assert_array_equal(radii, oradii)
-    solid, touched = touched_by_fragile(o)
+    solid, touched, bounds = fragile_bounds(o, dpix)
     err = np.abs(img - oimg).max(0)
     og = {rename.get(k, k): v for k, v in o.backward(dpix).items()}
     og = {k: og[k] for k in grads}
     vis = oradii > 0
-    parity_report(name, img, oimg, grads, og, solid, touched, visible=vis)
+    parity_report(name, img, oimg, grads, og, solid, touched, visible=vis, bounds=bounds)
     assert solid.mean() > 0.99 and err[solid].max() <= RGB_TOL, "max err %.3e" % err[solid].max()
     assert err.max() <= 2.0 / 255 * max(1.0, float(np.abs(oimg).max())) + 1e-3
     flat = {k: v.reshape(v.shape[0], -1) for k, v in grads.items()}
-    assert_grad_parity(flat, {k: og[k].reshape(og[k].shape[0], -1) for k in og}, touched, vis)
+    assert_grad_parity(flat, {k: og[k].reshape(og[k].shape[0], -1) for k in og}, touched, vis, bounds=bounds)
     for k in grads:
         assert np.abs(og[k]).max() > 0, k
     return og
@@ -123,13 +123,13 @@ def test_config5_sh_degree_3_full_size():
     img, radii, grads, _ = hip_render(g, dpix, shs=shs, sh_degree=3)
     o, oimg, oradii = _oracle(g, "f32", shs=shs, degree=3)
     np.testing.assert_array_equal(radii, oradii)
-    solid, touched = touched_by_fragile(o)
+    solid, touched, bounds = fragile_bounds(o, dpix)
     err = np.abs(img - oimg).max(0)
     og = o.backward(dpix)
     og = {k: og[k] for k in grads}
-    parity_report("config5_2048_2p4M_sh3", img, oimg, grads, og, solid, touched, visible=oradii > 0)
+    parity_report("config5_2048_2p4M_sh3", img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
     assert solid.mean() > 0.998 and err[solid].max() <= RGB_TOL and (err > RGB_TOL).sum() <= 400
-    _assert_full_size_grads({k: v.reshape(n, -1) for k, v in grads.items()}, {k: v.reshape(n, -1) for k, v in og.items()}, touched)
+    _assert_full_size_grads({k: v.reshape(n, -1) for k, v in grads.items()}, {k: v.reshape(n, -1) for k, v in og.items()}, touched, bounds)
     assert np.abs(grads["shs"]).max() > 0
     _, _, grads2, _ = hip_render(g, 2 * dpix, shs=shs, sh_degree=3)
     for k in grads:

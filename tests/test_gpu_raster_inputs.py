@@ -11,7 +11,7 @@
 import numpy as np
 import pytest
 
-from conftest import assert_grad_parity, hip_render, oracle_render, parity_report, simple_scene, touched_by_fragile
+from conftest import assert_grad_parity, fragile_bounds, hip_render, oracle_render, parity_report, simple_scene, touched_by_fragile
 
 pytestmark = pytest.mark.gpu
 
@@ -38,8 +38,8 @@ def test_gradscaler_loss_scale_is_exact(family, bg):
     # and the scaled gradients still equal the oracle's on the scaled seed (nothing saturates at the GradScaler's magnitudes)
     o, _, oradii = oracle_render(g, "f32")
     og = o.backward(65536.0 * dpix)
-    _, touched = touched_by_fragile(o)
-    assert_grad_parity(g2, og, touched, oradii > 0)
+    _, touched, bounds = fragile_bounds(o, 65536.0 * dpix)
+    assert_grad_parity(g2, og, touched, oradii > 0, bounds=bounds)
 
 
 def test_nonblack_background_at_config2_size(family):
@@ -51,13 +51,13 @@ def test_nonblack_background_at_config2_size(family):
     img, radii, grads, _ = hip_render(g, dpix)
     o, oimg, oradii = oracle_render(g, "f32")
     np.testing.assert_array_equal(radii, oradii)
-    solid, touched = touched_by_fragile(o)
+    solid, touched, bounds = fragile_bounds(o, dpix)
     err = np.abs(img - oimg).max(0)
     og = o.backward(dpix)
-    parity_report("config2_colour_background[%s]" % family, img, oimg, grads, og, solid, touched, visible=oradii > 0)
+    parity_report("config2_colour_background[%s]" % family, img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
     assert solid.mean() > 0.998 and err[solid].max() <= RGB_TOL and (err > RGB_TOL).sum() <= 100
     assert float(np.abs(img[:, 0, 0] - g["bg"]).max()) == 0.0           # an empty corner pixel shows the background exactly
-    _assert_full_size_grads(grads, og, touched)
+    _assert_full_size_grads(grads, og, touched, bounds)
     assert ((oradii > 0) & ~touched).sum() >= 0.5 * (oradii > 0).sum()
     # the background term is live: the same scene on black gives different opacity gradients
     g0 = dict(g); g0["bg"] = np.zeros(3, np.float32)
@@ -92,15 +92,15 @@ def test_splat_centres_exactly_on_pixel_centres(family):
     on_centre = (xy[vis] == np.round(xy[vis])).all(1)
     assert on_centre.mean() > 0.99, on_centre.mean()                      # the construction really snaps the centres
     # compare EVERYTHING the alpha / T thresholds leave solid -- including the centre pixels, where power == 0 exactly
-    solid, touched = touched_by_fragile(o, power_band=0.0)
+    solid, touched, bounds = fragile_bounds(o, dpix, power_band=0.0)
     solid_default, _ = touched_by_fragile(o)                              # the default band also flags |power| < 1e-6: reported
     err = np.abs(img - oimg).max(0)
     og = o.backward(dpix)
     parity_report("pixel_centre_snapped[%s]" % family, img, oimg, grads, og, solid, touched, visible=vis,
-                  extra=dict(pixels_flagged_by_power_band=int((solid & ~solid_default).sum()), centres_on_pixel_centres=float(on_centre.mean())))
+                  extra=dict(pixels_flagged_by_power_band=int((solid & ~solid_default).sum()), centres_on_pixel_centres=float(on_centre.mean())), bounds=bounds)
     assert (solid & ~solid_default).sum() > 1000                           # thousands of pixels carry a pair with power == 0 ...
     assert solid.mean() > 0.98 and err[solid].max() <= RGB_TOL, err[solid].max()   # ... and every one of them agrees with the oracle
-    assert_grad_parity(grads, og, touched, vis)
+    assert_grad_parity(grads, og, touched, vis, bounds=bounds)
 
 
 def test_render_batch_with_samples_of_very_different_size(monkeypatch):
