@@ -67,25 +67,39 @@ def gpu_numa_cpus(device_index):
         return None
 
 
-def set_cpu_affinity(local_rank, local_world, device_index=None):
+def set_cpu_affinity(local_rank, local_world, device_index=None, peer_device_indices=None):
     """One process per GPU, and every process is host-bound in bursts (six HIP streams of launches per rank in bench.py, the DataLoader workers of
     the trainer): pin each rank to its own slice of the CPUs -- those of its GPU's NUMA node when sysfs names one, else an even split of whatever
     this process may run on -- so that 8 ranks do not migrate across sockets or pile onto the same cores.  GPSGS_AFFINITY=0 switches it off.
+    peer_device_indices: the device index of every LOCAL rank (default: rank r drives device r, which is what torchrun + LOCAL_RANK gives); pass it
+    when the mapping differs.  local_world must be the number of ranks ON THIS NODE: if the launcher did not say (no LOCAL_WORLD_SIZE) and the
+    caller fell back to the world size of a multi-node job, the slices would be 1 / world of the node -- so a local_world larger than the visible
+    GPU count is refused (returns None, with a warning) instead of idling most cores.  After pinning, torch's intra-op pool is sized to the slice
+    (it was sized for the whole machine at import time; N threads squeezed onto cores / N CPUs thrash).
     Returns the CPU set chosen (or None: left alone)."""
     if os.environ.get("GPSGS_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity") or local_world <= 1:
         return None
     try:
+        n_vis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_vis and local_world > n_vis and "LOCAL_WORLD_SIZE" not in os.environ:
+            print("gps_gaussian_amd.dist: %d ranks but %d visible GPUs and no LOCAL_WORLD_SIZE: not pinning CPUs (the local rank count is unknown)" % (local_world, n_vis))
+            return None
         allowed = sorted(os.sched_getaffinity(0))
         node = gpu_numa_cpus(device_index) if device_index is not None else None
         pool = sorted(set(allowed) & node) if node else allowed
         # ranks that share a pool (same NUMA node, or no topology information: everybody) split it evenly, in local-rank order
         sharers, me = local_world, local_rank
         if node:
-            same = [r for r in range(local_world) if (gpu_numa_cpus(r) or set()) == node]
+            peers = list(peer_device_indices) if peer_device_indices is not None else list(range(local_world))
+            same = [r for r in range(local_world) if (gpu_numa_cpus(peers[r]) or set()) == node]
             sharers, me = max(1, len(same)), (same.index(local_rank) if local_rank in same else 0)
         per = max(1, len(pool) // sharers)
         mine = pool[me * per:(me + 1) * per] or pool
         os.sched_setaffinity(0, mine)
+        try:
+            torch.set_num_threads(max(1, len(mine)))
+        except Exception:  # noqa: BLE001
+            pass
         return set(mine)
     except Exception:  # noqa: BLE001
         return None
@@ -130,7 +144,17 @@ class GradAllReducer:
         layers is still running; `reducer()` then only launches what the hooks could not (buckets holding parameters that received no gradient:
         the reference constructs but never uses gru16 / gru32, core/update.py:105-106 -- they travel as zeros, so every rank issues identical
         collectives), waits, and writes the means back.  Smaller buckets (8 MiB: ~3 messages) give the overlap something to start early.
-    Both produce the same numbers (tests/test_multiproc_gloo.py)."""
+    Both produce the same numbers (tests/test_multiproc_gloo.py).
+
+    Contract of overlap=True: collectives are ISSUED IN BUCKET ORDER on every rank whatever order autograd completes the buckets in
+    (a bucket whose gradients are complete waits for the buckets in front of it), so ranks whose data-dependent branches finish parameters in a
+    different order -- or leave some without a gradient -- still issue identical sequences (what the hooks could not start, `reducer()` starts, in
+    the same order).  Which parameters a bucket waits for is LEARNT at the first `reducer()` call -- the parameters that received a gradient on
+    ANY rank (one small MAX all-reduce of the mask; the reference's never-used gru16 / gru32 drop out, so their buckets do not hold the others
+    back) -- and the first step therefore runs without overlap.  A bucket that receives gradients again after its all-reduce was started -- a second backward before `reducer()` (gradient
+    accumulation), or a step whose `reducer()` call was skipped after an exception -- is marked dirty: `reducer()` waits for the stale collective,
+    discards it and reduces the bucket again from the accumulated gradients.  `reset()` drops all in-flight state explicitly (call it after a
+    backward that raised, on EVERY rank)."""
 
     def __init__(self, params, bucket_bytes=None, overlap=False):
         self.params = [p for p in params if p.requires_grad]
@@ -149,13 +173,17 @@ class GradAllReducer:
         if cur:
             self.buckets.append(cur)
         self._ready = [0] * len(self.buckets)
-        self._inflight = {}  # bucket index -> (flat tensor, work handle, event)
+        self._inflight = {}  # bucket index -> (flat tensor, work handle)
+        self._dirty = set()  # buckets whose in-flight collective no longer holds their current gradients
+        self._next = 0       # overlap: the next bucket the hooks may start (issue order = bucket order on every rank)
+        self._expect = None  # overlap: per bucket, the ids of the parameters it waits for (learnt at the first call, identical on every rank)
+        self._got = set()    # ids of the parameters whose gradient has arrived since the last call
         self._comm = None
         self._hooks = []
         if self.overlap:
             where = {id(p): b for b, bucket in enumerate(self.buckets) for p in bucket}
             for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(lambda t, b=where[id(p)]: self._on_grad(b)))
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda t, b=where[id(p)], k=id(p): self._on_grad(b, k)))
 
     def _active(self):
         return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
@@ -175,19 +203,47 @@ class GradAllReducer:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         self._inflight[b] = (flat, work)
 
-    def _on_grad(self, b):
+    def _on_grad(self, b, key):
         if not self._active():
             return
         self._ready[b] += 1
-        if self._ready[b] == len(self.buckets[b]) and b not in self._inflight:
-            self._launch(b)
+        again = key in self._got
+        self._got.add(key)
+        if b in self._inflight:  # a gradient arrived AFTER this bucket's all-reduce was started (second backward / a skipped reducer() call /
+            self._dirty.add(b)   # a parameter the bucket did not wait for)
+            return
+        if again or self._expect is None:  # accumulating into a bucket that has not left yet is fine; nothing starts before the first call
+            return
+        while self._next < len(self.buckets) and self._next not in self._inflight and self._expect[self._next] <= self._got:
+            self._launch(self._next)  # in bucket order only: a completed bucket waits for the ones in front of it
+            self._next += 1
+
+    def reset(self):
+        """Drop every in-flight collective and all hook state (waits for what was started, so that no rank leaves a collective half-issued)."""
+        for b in sorted(self._inflight):
+            self._inflight[b][1].wait()
+        self._inflight.clear()
+        self._dirty.clear()
+        self._ready = [0] * len(self.buckets)
+        self._got.clear()
+        self._next = 0
 
     @torch.no_grad()
     def __call__(self):
         if not self._active():
             return
         world = dist.get_world_size()
-        for b in range(len(self.buckets)):  # whatever the hooks did not start (overlap off; or parameters without a gradient in the bucket)
+        if self.overlap and self._expect is None:
+            # learn what each bucket waits for: the parameters that received a gradient on ANY rank this step (identical on every rank afterwards)
+            ref = self.params[0]
+            mask = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], dtype=torch.float32, device=ref.device)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+            used = {id(p) for p, m in zip(self.params, mask.tolist()) if m > 0}
+            self._expect = [{id(p) for p in bucket if id(p) in used} for bucket in self.buckets]
+        for b in sorted(self._dirty):  # stale collectives: finish them (every rank issued them), throw the result away, reduce the bucket again
+            self._inflight.pop(b)[1].wait()
+        self._dirty.clear()
+        for b in range(len(self.buckets)):  # whatever the hooks did not start (overlap off; parameters without a gradient in the bucket; dirty ones)
             if b not in self._inflight:
                 self._launch(b)
         for b, bucket in enumerate(self.buckets):
@@ -202,6 +258,8 @@ class GradAllReducer:
                 p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
         self._ready = [0] * len(self.buckets)
+        self._got.clear()
+        self._next = 0
 
     def remove_hooks(self):
         for h in self._hooks:

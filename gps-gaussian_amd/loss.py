@@ -6,6 +6,8 @@ One forward launch pair and one backward launch replace ~30 eager kernels each w
 ground-truth image has no gradient in the reference either).  No CPU fallback."""
 import ctypes as C
 
+import threading
+
 import torch
 
 from . import _capi
@@ -60,23 +62,25 @@ def l1_and_ssim(pred, gt):
     return _L1SSIM.apply(pred, gt)
 
 
-_shared = None  # (weakref pred, pred._version, weakref gt, gt._version, grad mode, (l1, ssim)) of the latest fused forward
+_shared = threading.local()  # .entry = (weakref pred, pred._version, weakref gt, gt._version, grad mode, (l1, ssim)) of THIS THREAD's latest fused forward
 
 
 def l1_and_ssim_shared(pred, gt):
     """l1_and_ssim for callers that ask for the two numbers in two calls on the SAME tensors (train_stage2.py:70-71: `l1_loss(render, gt)`
     then `ssim(render, gt)`): the second call gets the other output of the first call's fused forward -- one forward and one backward launch
-    pair instead of two.  Same tensor OBJECTS, unchanged since (version counters) and the same grad mode, or it is computed afresh.  The pair of
-    0-d outputs is kept until the next call; their graph's saved maps are released by the backward as usual."""
+    pair instead of two.  Same tensor OBJECTS, unchanged since (version counters) and the same grad mode, or it is computed afresh.
+    SINGLE USE: the pair is handed out once more and then dropped -- a third evaluation of the same unchanged tensors (e.g. after a
+    backward has freed the first pair's graph) computes afresh instead of returning outputs whose graph is gone, and nothing keeps the autograd
+    graph and its saved SSIM maps alive between iterations.  Per host thread (two threads computing losses must not cross-talk)."""
     import weakref
 
-    global _shared
-    s = _shared
+    s = getattr(_shared, "entry", None)
+    _shared.entry = None
     if (s is not None and s[0]() is pred and s[2]() is gt and s[1] == pred._version and s[3] == gt._version
             and s[4] == torch.is_grad_enabled()):
         return s[5]
     out = _L1SSIM.apply(pred, gt)
-    _shared = (weakref.ref(pred), pred._version, weakref.ref(gt), gt._version, torch.is_grad_enabled(), out)
+    _shared.entry = (weakref.ref(pred), pred._version, weakref.ref(gt), gt._version, torch.is_grad_enabled(), out)
     return out
 
 

@@ -98,10 +98,24 @@ def _composite_flag():
 _DEFAULT_FAMILY = "tiles"
 
 
-def _wave_priority_flag():
-    """GSR_FLAG_WAVE_PRIORITY unless GPSGS_WAVE_PRIORITY=0 (include/gpsgs.h: hardware wave priorities in the tile compositing kernels; results
-    unchanged)."""
-    return 0 if os.environ.get("GPSGS_WAVE_PRIORITY", "1") == "0" else _capi.GSR_FLAG_WAVE_PRIORITY
+def _wave_priority_flag(st=None, stream=None):
+    """GSR_FLAG_WAVE_PRIORITY (include/gpsgs.h: hardware wave priorities in the tile compositing kernels; results unchanged) for a view that has
+    the chip to itself.  GPSGS_WAVE_PRIORITY=0 / 1 forces it off / on; default (unset): on, unless this device saw rasteriser calls on MORE THAN ONE
+    stream within the last 50 ms -- user code that spreads views over streams overlaps their kernels, where the scheme costs ~2 % of the
+    aggregate rate instead of gaining 4 - 8 %."""
+    env = os.environ.get("GPSGS_WAVE_PRIORITY")
+    if env == "0":
+        return 0
+    if env is None and st is not None and stream is not None:
+        now = time.perf_counter()
+        seen = st.setdefault("streams", {})
+        seen[stream] = now
+        if len(seen) > 1:
+            for k in [k for k, t in seen.items() if now - t > 0.05]:
+                del seen[k]
+            if len(seen) > 1:
+                return 0
+    return _capi.GSR_FLAG_WAVE_PRIORITY
 
 
 def _check_mode():
@@ -117,7 +131,8 @@ def _drain_pending(st, block=False):
     header at the END of the forward, so the blocking drain in the backward waited for the whole forward and deferred ran SLOWER than sync) -- and
     ("ev", ...) -- a header copy + event at the end of the forward (GPSGS_EARLY_NOTIFY=0)."""
     keep = []
-    pending, st["pending"] = st["pending"], []
+    with _lock:  # the swap is atomic with respect to other threads' drains and appends (an autograd thread's backward drains too)
+        pending, st["pending"] = st["pending"], []
     try:
         for i, ent in enumerate(pending):
             if ent[0] == "note":
@@ -130,6 +145,7 @@ def _drain_pending(st, block=False):
                         _wait_notify(w32, seq, stream)
                     except Exception:
                         _rings[(dev_index, "notify")].release(slot)
+                        keep.extend(pending[i + 1:])  # the entries behind this one stay pending: their slots and capacity results are not lost
                         raise
                 R, overflow, need = _decode(hdr)
                 npts, longest = int(w32[6]), int(w32[3])
@@ -149,11 +165,12 @@ def _drain_pending(st, block=False):
             if overflow:
                 keep.extend(pending[i + 1:])  # (their slots are looked at -- and released -- by the next call)
                 raise RuntimeError(
-                    "gps_gaussian_amd: a previous rasteriser call (GPSGS_CHECK=deferred) needed %d instances, more than its "
-                    "capacity (or met a bin list longer than this device had seen); that image was not rendered. Capacity has been raised; re-run, "
-                    "or use GPSGS_CHECK=sync." % R)
+                    "gps_gaussian_amd: a previous rasteriser call (GPSGS_CHECK=deferred) was not rendered: it needed %d (Gaussian, bin) instances / "
+                    "gradient slots (its workspace had room for fewer) and its longest bin list was %d entries. Capacity has been raised; re-run, "
+                    "or use GPSGS_CHECK=sync." % (need, longest if ent[0] == "note" else (int(hdr[1]) >> 32) & 0xffffffff))
     finally:
-        st["pending"] = keep + st["pending"]
+        with _lock:
+            st["pending"] = keep + st["pending"]
 
 
 def _decode(hdr):
@@ -422,11 +439,11 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
     bg = _cam(rs.bg, 3, dev)
     # the compositing family and, for a view rendered on its own (the GaussianRasterizer module: no row range), the wave-priority scheme --
     # it pays when the view's kernels have the chip to themselves; a batch spreads its views over several streams and leaves it off
-    family = _composite_flag() | (_wave_priority_flag() if rows is None else 0)
+    st = _dev_state(dev)
+    family = _composite_flag() | (_wave_priority_flag(st, torch._C._cuda_getCurrentRawStream(dev.index)) if rows is None else 0)
     extra = _extra_flags  # read ONCE per view and carried to its backward in ctx (the backward runs on an autograd thread)
     base_flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | extra | family
     mode = _check_mode()
-    st = _dev_state(dev)
     if mode != "none" and torch.cuda.is_current_stream_capturing():
         raise RuntimeError("gps_gaussian_amd: the capacity check reads a header back on the host and cannot run under graph capture; "
                            "warm up eagerly, then capture with GPSGS_CHECK=none")
@@ -457,6 +474,7 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
         def launch(cap):
             """Enqueue the whole forward against an instance capacity.  -> (workspace, bytes, notify slot or None)"""
             nbytes = ws_bytes(P, W, H, cap)
+            st["last_ws_bytes"] = nbytes  # reported by last_stats(): what one view in flight holds (forward-only workspaces are ~3x smaller)
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             flags, note = base_flags, None
             hdr_ptr, seq = None, 0
@@ -467,7 +485,9 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
                 # surprise is reported like an overflow
                 slot, hdr, w32, hdr_ptr, seq = ring.acquire_notify()
                 note = (slot, hdr, w32, seq)
-                if not st.get("big_bins", False):
+                # (only where a repair loop exists: sync mode, also inside defer_capacity_checks().  Deferred mode cannot re-run the view, so it always
+                #  launches the large-list sorts -- they return at once when the view's longest list is short: ADVICE r04)
+                if mode == "sync" and not st.get("big_bins", False):
                     flags |= _capi.GSR_FLAG_NO_LARGE_SORT
             ext = _ext(rows, st.get("longest", 0), appear)  # work order: longest lists first, relative to the longest list seen on this device
             rc = lib.gsr_forward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier), float(rs.tanfovx),
@@ -523,7 +543,8 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
                     break
                 if mode == "deferred":
                     # never blocks: the notification (it lands ~40 us into this forward) is looked at by the next call on this device
-                    st["pending"].append(("note", note, cur_stream, P if rows is None else None, dev.index))
+                    with _lock:
+                        st["pending"].append(("note", note, cur_stream, P if rows is None else None, dev.index))
                     break
                 if not settle(note, cap)[0]:
                     break
@@ -538,7 +559,8 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             _capi.check(lib.gsr_copy_header_async(_ptr(ws), hdr_ptr, stream), "gsr_copy_header_async")
             ev.record(cur_stream)
             if mode == "deferred":
-                st["pending"].append(("ev", ev, hdr, P if rows is None else None))
+                with _lock:
+                    st["pending"].append(("ev", ev, hdr, P if rows is None else None))
                 break
             ev.synchronize()
             R, overflow, need = _decode(hdr)
@@ -673,7 +695,8 @@ class GaussianRasterizer(nn.Module):
 
 
 def last_stats(device=None):
-    """Capacity-policy state (instances-per-Gaussian ratio seen, capacity floor) for diagnostics."""
+    """Capacity-policy state (instances-per-Gaussian ratio seen, capacity floor, bytes of the last workspace = what one view in flight holds)
+    for diagnostics."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     return dict(_dev_state(dev), pending=len(_dev_state(dev)["pending"]))
 

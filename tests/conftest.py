@@ -170,7 +170,7 @@ def parity_report(name, img, oimg, grads, og, solid, touched, extra=None, rgb_to
     return rep
 
 
-def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2e-3, strict_min=0.5, strict_max_over=0, bounds=None):
+def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2e-3, strict_min=0.5, strict_max_over=0, bounds=None, strict_cap=None):
     """The gradient criterion every parity test applies (so that every one of them can FAIL):
       * STRICT: the visible Gaussians that take part in no fragile pixel (fragile_bounds) are within grad_tol (normalised error
         |a - ref| / (|ref| + grad_tol max|ref|)), at most strict_max_over of them excepted;
@@ -193,6 +193,8 @@ def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2
             k, int(over.sum()), over.size, grad_tol, frac)
         assert int((over & strict).sum()) <= strict_max_over, "%s: %d strict-set Gaussians over %g (max err %.3e)" % (
             k, int((over & strict).sum()), grad_tol, e[strict].max())
+        if strict_cap is not None and strict.any():
+            assert e[strict].max() <= strict_cap * grad_tol, "%s: a strict-set Gaussian is off by %.3e (cap %g x %g)" % (k, e[strict].max(), strict_cap, grad_tol)
         if bounds is not None:
             ratio = (d / _allowed(og[k], bounds.get(k), grad_tol)).reshape(d.shape[0], -1).max(axis=-1)
             bad = (ratio > 1.0) & touched

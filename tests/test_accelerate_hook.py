@@ -130,3 +130,25 @@ def test_a_typo_in_the_feature_list_raises(tmp_path):
     assert A.requested("") == () and A.requested("all") == A.FEATURES and A.requested("loss, pack") == ("pack", "loss")
     with pytest.raises(ValueError):
         A.requested("pack,los")
+
+
+def test_calls_handed_on_to_the_reference_are_counted(tmp_path):
+    """A configuration the fused kernels do not implement goes to the reference's own function -- and leaves a trace in `calls`."""
+    out = _run("""
+        import train_stage2  # noqa: F401
+        import torch
+        import gps_gaussian_amd.accelerate as A
+        import lib.loss, lib.utils
+        a, b = torch.rand(1, 3, 24, 24), torch.rand(1, 3, 24, 24)
+        assert A.calls["loss_passthrough"] == 0 and A.calls["unproject_passthrough"] == 0
+        v = lib.loss.ssim(a, b, window_size=7)                     # not the fused configuration: the reference's eager ssim, on the CPU tensors
+        assert 0.0 < float(v) < 1.0 and A.calls["loss_passthrough"] == 1 and A.calls["loss"] == 0
+        m = lib.loss.ssim(a, b, size_average=False)
+        assert m.numel() == 1 and A.calls["loss_passthrough"] == 2
+        depth = torch.rand(1, 1, 8, 8) + 0.5
+        extr = torch.eye(4)[:3].unsqueeze(0); intr = torch.eye(3).unsqueeze(0)
+        pts = lib.utils.depth2pc(depth, extr, intr)                # a depth map that did not come from the fused flow2depth
+        assert pts.shape == (1, 64, 3) and A.calls["unproject_passthrough"] == 1 and A.calls["unproject"] == 0
+        print("PASSTHROUGH_OK")
+    """, "all", tmp_path)
+    assert "PASSTHROUGH_OK" in out

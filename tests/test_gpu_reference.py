@@ -257,6 +257,7 @@ def test_view_interp_script_with_the_import_hook_writes_the_same_views(tmp_path)
     out_hook = {f: np.asarray(Image.open(tmp_path / "w" / "interp_out" / f)).astype(np.int32) for f in sorted(os.listdir(tmp_path / "w" / "interp_out"))}
     assert a["accelerate"]["calls"] == {} and b["accelerate"]["calls"]["pack"] == 18 and b["accelerate"]["calls"]["loss"] == 0, (a["accelerate"], b["accelerate"])
     assert b["accelerate"]["calls"]["corr"] == 18 and b["accelerate"]["calls"]["unproject"] == 36 and b["accelerate"]["calls"]["upsample"] == 18
+    assert b["accelerate"]["calls"]["loss_passthrough"] == 0 and b["accelerate"]["calls"]["unproject_passthrough"] == 0   # nothing fell through to the eager functions
     assert sorted(out_plain) == sorted(out_hook) and len(out_plain) == 6
     stats = {}
     for f in out_plain:
@@ -344,6 +345,7 @@ def test_train_stage2_reaches_the_fused_kernels_through_the_import_hook(tmp_path
     # GRU iteration in training (3 iterations: raft.train_iters) and once per validation forward
     assert acc["calls"]["pack"] == 7 and acc["calls"]["loss"] == 12 and acc["calls"]["unproject"] == 14 and acc["calls"]["upsample"] >= 6 * 3 + 1, acc["calls"]
     assert acc["calls"]["corr"] == 7, acc["calls"]   # one correlation block per model forward
+    assert acc["calls"]["loss_passthrough"] == 0 and acc["calls"]["unproject_passthrough"] == 0, acc["calls"]   # no call fell through to the reference's eager functions
     for r in (plain, fused):
         assert r["total_steps"] == 6 and r["finite_weights"] and len(r["metrics"]) == 6 and len(r["evals"]) == 1 and r["evals"][0]["val_psnr"] > 0, r
     def spread(x, y):

@@ -58,18 +58,69 @@ WORKER = textwrap.dedent("""
     red2 = D.GradAllReducer(params, bucket_bytes=300, overlap=True)
     assert len(red2.buckets) > 1 and red2.buckets[0][0] is params[-1]
     net(x).sum().backward()
-    started = len(red2._inflight)               # collectives already in flight when backward() returns
+    assert not red2._inflight                   # the first step learns which parameters ever receive a gradient: nothing starts early
     red2()
-    assert started >= 1 and not red2._inflight
+    assert red2._expect is not None and set().union(*red2._expect) == {id(p) for p in net.parameters()}       # the unused layer is waited for by nobody
     for p, want in zip(params, serial):
         assert p.grad is not None and torch.equal(p.grad, want), (p.shape, (p.grad - want).abs().max())
-    # a second iteration through the same hooks (counters reset by the call)
+    # a second iteration through the same hooks: now the collectives start DURING the backward, in bucket order
+    for p in params:
+        p.grad = None
+    net(x).sum().backward()
+    started = sorted(red2._inflight)            # collectives already in flight when backward() returns
+    red2()
+    assert len(started) >= 2 and started == list(range(len(started))) and not red2._inflight, started
+    for p, want in zip(params, serial):
+        assert torch.equal(p.grad, want)
+    # --- ADVICE r04 hazards of the overlapped form ---------------------------------------------------------------------------------
+    # (1) gradient accumulation: TWO backwards before reducer(): the collectives the hooks started after the first one are stale; the result must be
+    #     the mean of the ACCUMULATED gradients
+    for p in params:
+        p.grad = None
+    net(x).sum().backward()
+    net(x).sum().backward()
+    assert red2._dirty, "the second backward must mark the buckets already in flight"
+    red2()
+    for p, want in zip(params, serial):
+        assert torch.allclose(p.grad, 2 * want, atol=1e-6), (p.shape, (p.grad - 2 * want).abs().max())
+    assert not red2._dirty and not red2._inflight and red2._next == 0
+    # (2) a step whose reducer() call was skipped (an exception between backward and the exchange): the next step must not write stale means back
+    for p in params:
+        p.grad = None
+    net(3 * x).sum().backward()        # ... reducer() never called for this one; the caller drops the gradients and carries on
     for p in params:
         p.grad = None
     net(x).sum().backward()
     red2()
     for p, want in zip(params, serial):
-        assert torch.equal(p.grad, want)
+        assert torch.allclose(p.grad, want, atol=1e-6)
+    # explicit reset() after a failed step does the same
+    for p in params:
+        p.grad = None
+    net(3 * x).sum().backward()
+    red2.reset()
+    assert not red2._inflight and red2._next == 0
+    for p in params:
+        p.grad = None
+    net(x).sum().backward()
+    red2()
+    for p, want in zip(params, serial):
+        assert torch.allclose(p.grad, want, atol=1e-6)
+    # (3) data-dependent parameter usage: rank 1 also runs `unused` (rank 0 does not), so the ranks complete their buckets in different orders and
+    #     rank 0 never completes some of them; every rank must still ISSUE the same sequence of collectives (no hang), result = mean over ranks
+    for p in params:
+        p.grad = None
+    y = net(x)
+    if rank == 1:
+        y = unused(y)
+    y.sum().backward()
+    mine_g = [(p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in params]
+    red2()
+    both = [None, None]
+    dist.all_gather_object(both, [g.tolist() for g in mine_g])
+    for p, g0, g1 in zip(params, both[0], both[1]):
+        assert torch.allclose(p.grad, (torch.tensor(g0) + torch.tensor(g1)) / 2, atol=1e-6)
+    assert float(sum(p.grad.abs().sum() for p in unused.parameters())) > 0
     red2.remove_hooks()
     # --- CPU affinity helper: every rank gets a non-empty slice of what it may run on; two ranks sharing one pool get disjoint slices when there are >= 2 CPUs
     before = sorted(os.sched_getaffinity(0))
