@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpsgs_hip.so")
+LIB_PATH = os.environ.get("GPSGS_LIB") or os.path.join(_HERE, "lib", "libgpsgs_hip.so")  # GPSGS_LIB: development (another build of the same library)
 
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (

@@ -25,7 +25,7 @@ _PREFIXES = ("lib", "core", "gaussian_renderer", "config", "train_stage2", "test
 
 calls = {f: 0 for f in FEATURES}
 # calls that went THROUGH a replacement but were handed on to the reference's own function (a configuration the fused kernel does not implement):
-# counted, so that a run on the eager path for those calls leaves a trace; tools/run_reference.py prints them
+# counted, so that a run on the eager path for those calls leaves a trace; the full-pipeline runner prints them
 calls["loss_passthrough"] = 0
 calls["unproject_passthrough"] = 0
 _installed = {}          # "module.attr" -> feature

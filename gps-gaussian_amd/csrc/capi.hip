@@ -154,19 +154,20 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     }
     GsrHeader *hdr = reinterpret_cast<GsrHeader *>(at(workspace, L.header));
     uint32_t *bin_count = reinterpret_cast<uint32_t *>(at(workspace, L.bin_count));
+    uint32_t *bin_count_fb = reinterpret_cast<uint32_t *>(at(workspace, L.bin_count_fb));
     uint32_t *bin_offset = reinterpret_cast<uint32_t *>(at(workspace, L.bin_offset));
     uint32_t *bin_cursor = reinterpret_cast<uint32_t *>(at(workspace, L.bin_cursor));
     uint32_t *wg_order = reinterpret_cast<uint32_t *>(at(workspace, L.wg_order));
     uint4 *scan_part = reinterpret_cast<uint4 *>(at(workspace, L.scan_part));
     GsrSplat *splats = reinterpret_cast<GsrSplat *>(at(workspace, L.splats));
-    uint32_t *hitmask = reinterpret_cast<uint32_t *>(at(workspace, L.hitmask));
+    uint4 *binrec = reinterpret_cast<uint4 *>(at(workspace, L.binrec));
     uint32_t *wg_tab = reinterpret_cast<uint32_t *>(at(workspace, L.wg_tab));
     uint64_t *keys = reinterpret_cast<uint64_t *>(at(workspace, L.keys));
     uint32_t *point_list = reinterpret_cast<uint32_t *>(at(workspace, L.point_list));
     float *final_T = reinterpret_cast<float *>(at(workspace, L.final_T));
     uint32_t *n_contrib = reinterpret_cast<uint32_t *>(at(workspace, L.n_contrib));
 
-    // header + scan partials (their ready flags) + bin_count are adjacent: one memset
+    // header + scan partials (their ready flags) + bin_count + bin_count_fb are adjacent: one memset
     if (hipMemsetAsync(hdr, 0, L.bin_offset - L.header, s) != hipSuccess) return GPSGS_E_LAUNCH;
     if (P == 0) {  // upstream returns its zero-initialised image (NOT the background) when there is nothing to draw
         if (hipMemsetAsync(out_color, 0, sizeof(float) * 3 * (size_t)width * height, s) != hipSuccess) return GPSGS_E_LAUNCH;
@@ -192,20 +193,20 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     {
         trace("preprocess", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_PREPROCESS, s);
-        gsr_launch_preprocess(q, splats, hitmask, wg_tab, bin_count, hdr, s);
+        gsr_launch_preprocess(q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         trace("scan", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_SCAN, s);
-        gsr_launch_scan(bin_count, bin_offset, bin_cursor, wg_order, scan_part, L.NB, L.bx, L.by, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
+        gsr_launch_scan(bin_count, bin_count_fb, bin_offset, bin_cursor, wg_order, scan_part, L.NB, L.bx, L.by, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
                         (flags & GSR_FLAG_NO_LARGE_SORT) != 0, order_hint, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {
         trace("scatter", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, row_range, L.bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, s);
+        gsr_launch_scatter(P, row_range, L.bx, splats, binrec, wg_tab, bin_offset, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     {

@@ -3,13 +3,14 @@
 // Upstream builds one global list of (tile<<32 | depth) keys and radix-sorts all R of them through HBM (~6 passes
 // of 24 B/instance) after a blocking D2H read of R.  Here the bin part of the key is
 // resolved by construction instead of by sorting:
-//   k_scan_a/b two-phase parallel exclusive scan of the per-bin counts written by k_preprocess (normally fused into ONE launch:
-//              release flags + wait) -> bin_offset, cursors, R, overflow flag; R is published to the host from here.  The same pass
-//              emits wg_order: compositing workgroups with work first (so every CU starts on real work and the empty
-//              ones drain in the gaps), in image order within each class (keeps neighbouring bins on neighbouring CUs).
-//   k_scatter  each Gaussian drops (depth_bits<<32 | id) into its bins' segments; slots are reserved with ONE returning
-//              global atomic per (workgroup, bin), not one per instance; the per-workgroup bin table and the per-cell hit
-//              masks are the ones k_preprocess recorded (gsr_block_emit), nothing is recounted or re-tested.
+//   k_scan_a/b two-phase parallel exclusive scan of the per-bin counts written by k_preprocess (normally fused into ONE launch: the blocks exchange
+//              their partials as self-validating 64-bit atomics -- no release / acquire fence: round 5) -> bin_offset, cursors, R, overflow flag;
+//              R is published to the host from here.  The same pass emits wg_order: compositing workgroups with work first (so every CU starts
+//              on real work and the empty ones drain in the gaps), longest lists first, patch order inside a class.
+//   k_scatter  each Gaussian drops (depth_bits<<32 | id) into its bins' segments: slot = bin_offset[bin] + the base k_preprocess' count atomic
+//              returned for this workgroup (recorded in wg_tab) + the rank inside the workgroup (LDS atomic).  No global atomic, nothing
+//              recounted or re-tested (per-cell hit masks from k_preprocess).  512 threads x 2 Gaussians: every workgroup of a 600 k-Gaussian
+//              view is resident at once (one generation instead of two: the kernel is a latency chain, not a throughput problem).
 //   k_sort_*   one WAVE per bin sorts its segment with an ascending-only bitonic network on the 64-bit key, keys in
 //              registers, exchanges by DPP / LDS crossbar (lists <= 1024); longer lists get a 1024-thread workgroup in LDS.  Keys are unique (id in the low word) so the result is deterministic and equals
 //              upstream's stable radix order: depth ascending, ties by Gaussian index.
@@ -19,19 +20,27 @@
 
 namespace {
 
-constexpr int SB = GSR_SCAN_BLOCK;  // 1024 bins per scan block
-
 // Work order of the compositing / sorting waves: the bin grid enumerated in PATCHES of 8x8 bins (64x64 pixels; row-major inside a
 // patch, patches row-major).  A Gaussian is listed in ~3 neighbouring bins, mostly a 2x2 block: in this order the block's bins are
 // (with probability ~0.77) within 64 consecutive entries, which xcd_list_pos() hands to ONE XCD -- one L2 then fetches the splat
 // record once for all of them and merges the gradient records the compositing backward scatters into the Gaussian's (contiguous)
 // slots.  Image order (runs of 64x1 bins) shared only the horizontal neighbours.  -1: the index has no bin (ragged grid edge).
-__device__ __forceinline__ int tiled_bin(uint32_t t, int bx, int by) {
+__device__ __forceinline__ int gsr_tiled_bin(uint32_t t, int bx, int by) {
     const uint32_t pgx = ((uint32_t)bx + 7u) >> 3;
     const uint32_t p = t >> 6, w = t & 63u;
     const uint32_t x = (p % pgx) * 8u + (w & 7u), y = (p / pgx) * 8u + (w >> 3);
     return (x < (uint32_t)bx && y < (uint32_t)by) ? (int)(y * (uint32_t)bx + x) : -1;
 }
+// Work classes of a bin, by the length of its list relative to the longest list an earlier, similar view produced (GsrViewExt.order_hint; 0 =
+// unknown = every busy bin in class 0 = plain patch order): 0 = more than 1/2 of it, 1 = more than 1/4, 2 = any other busy bin, 3 = idle.
+// Dispatched in that order: a bin is ONE wave's sequential job and a SIMD gets only ~5 of them per kernel, so a 900-entry list that starts late
+// is what the other SIMDs end up waiting for (longest-processing-time-first, coarsely).  A performance hint only: every bin is handled exactly
+// once whatever its position.
+__device__ __forceinline__ int gsr_work_class(int wb, uint32_t wc, uint32_t hint) {
+    return wb < 0 ? -1 : (wc > (hint >> 1) ? 0 : (wc > (hint >> 2) ? 1 : (wc > 0u ? 2 : 3)));
+}
+
+constexpr int SB = GSR_SCAN_BLOCK;  // 1024 bins per scan block
 
 // block-wide exclusive scan of one uint per thread (1024 threads); returns the exclusive prefix, *total = block sum
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum /*[16]*/, uint32_t *total) {
@@ -56,30 +65,20 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum /*[1
     return woff + x - v;
 }
 
-// Work classes of a bin in the compositing / sort order, by the length of its list relative to the longest list an earlier, similar
-// view produced (hint: GsrViewExt.order_hint, a kernel argument; 0 = unknown = every busy bin in class 0 = plain patch order): class 0 = more than 1/2 of it, 1 = more than 1/4, 2 = any other busy bin, 3 = idle.  The classes are
-// dispatched in that order: a bin is ONE wave's sequential job and a SIMD gets only ~5 of them per kernel, so a 900-entry list that
-// starts late is what the other SIMDs end up waiting for (longest-processing-time-first, coarsely).  Two packed counters:
-// w0 = class 0 | class 1 << 16, w1 = class 2 | idle << 16 (each count <= 1024 per scan block).
-// The order is a performance hint only (every bin is handled exactly once whatever its position), so the threshold may be anything:
-// the caller passes what the header of an earlier forward reported (max_tile_count).
-__device__ __forceinline__ int work_class(int wb, uint32_t wc, uint32_t hint) {
-    return wb < 0 ? -1 : (wc > (hint >> 1) ? 0 : (wc > (hint >> 2) ? 1 : (wc > 0u ? 2 : 3)));
-}
 __device__ __forceinline__ uint32_t class_w0(int cls) { return cls == 0 ? 1u : (cls == 1 ? 0x10000u : 0u); }
 __device__ __forceinline__ uint32_t class_w1(int cls) { return cls == 2 ? 1u : (cls == 3 ? 0x10000u : 0u); }
 
 // phase A: per block of 1024 indices -> part[2 blk] = {sum of counts (bins in image order), w0 of the block's indices in WORK order
 // (tiled_bin), max count, -}, part[2 blk + 1].x = their w1
-__global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part, int NB, int bx, int by,
-                                               uint32_t hint) {
+__global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_count, const uint32_t *__restrict__ bin_count_fb, uint4 *__restrict__ part, int NB,
+                                               int bx, int by, uint32_t hint) {
     __shared__ uint32_t red[4][SB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x * SB + tid;
-    const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
-    const int wb = tiled_bin((uint32_t)b, bx, by);
-    const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] : 0u;
-    const int cls = work_class(wb, wc, hint);
+    const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] + bin_count_fb[(size_t)b * GSR_CPAD] : 0u;
+    const int wb = gsr_tiled_bin((uint32_t)b, bx, by);
+    const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] + bin_count_fb[(size_t)wb * GSR_CPAD] : 0u;
+    const int cls = gsr_work_class(wb, wc, hint);
     uint32_t s = c, nb = class_w0(cls), ni = class_w1(cls), mx = c;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(SB) void k_scan_a(const uint32_t *__restrict__ bin_
 // form is used).  Saves one launch.
 #define GSR_SCAN_FUSE_MAX 64
 template <bool FUSED>
-__global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, uint4 *__restrict__ part,
+__global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_count, const uint32_t *__restrict__ bin_count_fb, uint4 *__restrict__ part,
                                                uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
                                                uint32_t *__restrict__ wg_order, int NB, int bx, int by, int nblocks, int64_t cap,
                                                GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks,
@@ -118,10 +117,11 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     __shared__ uint32_t sp_idle[FUSED ? GSR_SCAN_FUSE_MAX : 1];
     const int tid = threadIdx.x;
     const int b = blockIdx.x * SB + tid;
-    const uint32_t c = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;
-    const int wb = tiled_bin((uint32_t)b, bx, by);  // the bin this thread places in the work order
-    const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] : 0u;
-    const int cls = work_class(wb, wc, hint);
+    const uint32_t c_rec = b < NB ? bin_count[(size_t)b * GSR_CPAD] : 0u;  // instances with a recorded base (k_preprocess' returning atomics)
+    const uint32_t c = c_rec + (b < NB ? bin_count_fb[(size_t)b * GSR_CPAD] : 0u);  // + those of workgroups whose bins did not fit the table
+    const int wb = gsr_tiled_bin((uint32_t)b, bx, by);  // the bin this thread places in the work order
+    const uint32_t wc = wb >= 0 ? bin_count[(size_t)wb * GSR_CPAD] + bin_count_fb[(size_t)wb * GSR_CPAD] : 0u;
+    const int cls = gsr_work_class(wb, wc, hint);
     // block 0 also owns the per-Gaussian slot prefix (training) and the header.  Neither depends on the other blocks' bins, so the
     // slot scan runs first -- under the wait for their partials -- and the header leaves (also towards the host) as soon as the
     // totals are known, before this block scans its own bins.
@@ -155,21 +155,28 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         }
         if (lane == 0) { red[0][wid] = s; red[1][wid] = nb; red[2][wid] = mx; red[3][wid] = ni; }
         __syncthreads();
+        // Each partial travels as TWO self-validating 64-bit words {sum | class 0 | class 1 | flag} and {max | class 2 | idle | flag}, written and
+        // read with RELAXED agent-scope atomics: data and ready flag share a word, so no ordering between addresses is needed -- and no release /
+        // acquire fence.  (A device-scope release is a write-back of the XCD's L2, which at this point holds k_preprocess' freshly written splat
+        // records, an acquire invalidates it: rounds 1-4 paid for both in the middle of a 16-workgroup latency chain -- measured 14.8 -> 10.8 us
+        // for this kernel.)  Class counts <= 1,024: 11 bits.
         if (tid == 0) {
             uint32_t ts = 0, tb = 0, tm = 0, ti = 0;
             for (int w = 0; w < SB / 64; w++) { ts += red[0][w]; tb += red[1][w]; tm = red[2][w] > tm ? red[2][w] : tm; ti += red[3][w]; }
-            uint32_t *me = reinterpret_cast<uint32_t *>(part + 2 * blockIdx.x);  // {sum, w0, max, flag | w1, -, -, -}
-            me[0] = ts; me[1] = tb; me[2] = tm; me[4] = ti;
-            __hip_atomic_store(me + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ready flag (zeroed by the forward's memset)
+            unsigned long long *me = reinterpret_cast<unsigned long long *>(part + 2 * blockIdx.x);
+            const unsigned long long A = (unsigned long long)ts | ((unsigned long long)(tb & 0xffffu) << 32) | ((unsigned long long)(tb >> 16) << 43) | (1ull << 63);
+            const unsigned long long B = (unsigned long long)tm | ((unsigned long long)(ti & 0xffffu) << 32) | ((unsigned long long)(ti >> 16) << 43) | (1ull << 63);
+            __hip_atomic_store(me, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(me + 1, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         slot_scan();  // after this block's partial is out, before the others' are needed
         if (tid < nblocks) {  // wait for every block's partial (all blocks are resident: nblocks <= GSR_SCAN_FUSE_MAX)
-            uint32_t *other = reinterpret_cast<uint32_t *>(part + 2 * tid);
-            while (__hip_atomic_load(other + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
-            sp[tid] = make_uint4(__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                 __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                 __hip_atomic_load(other + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1u);
-            sp_idle[tid] = __hip_atomic_load(other + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long *other = reinterpret_cast<unsigned long long *>(part + 2 * tid);
+            unsigned long long A, B;
+            while (((A = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull) __builtin_amdgcn_s_sleep(1);
+            while (((B = __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull) __builtin_amdgcn_s_sleep(1);
+            sp[tid] = make_uint4((uint32_t)A, (uint32_t)((A >> 32) & 0x7ffu) | ((uint32_t)((A >> 43) & 0x7ffu) << 16), (uint32_t)B, 1u);
+            sp_idle[tid] = (uint32_t)((B >> 32) & 0x7ffu) | ((uint32_t)((B >> 43) & 0x7ffu) << 16);
         }
         __syncthreads();
     }
@@ -195,23 +202,48 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
         if (host_hdr) {
             // early notification: the header goes straight to host-coherent pinned memory from here, so the host can check
             // capacity while scatter / sort / compositing are still running (no copy engine, no event in the stream)
-            const uint32_t ovf = ovf_b ? 1u : 0u;
-            volatile uint32_t *h = host_hdr;
-            h[0] = (uint32_t)tot_sum; h[1] = (uint32_t)(tot_sum >> 32); h[2] = ovf; h[3] = tot_max; h[4] = tot_busy; h[5] = tot_slots; h[6] = hdr->num_points;
-            __threadfence_system();
-            __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this word
+            // System-scope write-through stores, waited for (vmcnt counts stores on gfx9: zero = acknowledged by the fabric), THEN the sequence word the
+            // host polls -- not a system-scope release fence, which would write this XCD's whole L2 back first.
+            const uint32_t hv[7] = {(uint32_t)tot_sum, (uint32_t)(tot_sum >> 32), ovf_b ? 1u : 0u, tot_max, tot_busy, tot_slots, hdr->num_points};
+#pragma unroll
+            for (int k = 0; k < 7; k++) __hip_atomic_store(host_hdr + k, hv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    uint32_t blk_total;
-    const uint32_t off = pre_sum + block_exscan(c, wsum, &blk_total);
+    // ONE block scan of three words (this block's bin counts and the two packed class counters): the kernel is a latency chain, and three scans
+    // were six barriers
+    uint32_t off, r0, r1;
+    {
+        __shared__ uint32_t w3[3][SB / 64];
+        const int lane = tid & 63, wid = tid >> 6;
+        const uint32_t v[3] = {c, class_w0(cls), class_w1(cls)};
+        uint32_t x[3] = {v[0], v[1], v[2]};
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t y = __shfl_up(x[k], d, 64);
+                if (lane >= d) x[k] += y;
+            }
+        }
+        __syncthreads();
+        if (lane == 63) { w3[0][wid] = x[0]; w3[1][wid] = x[1]; w3[2][wid] = x[2]; }
+        __syncthreads();
+        uint32_t wo[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int w = 0; w < SB / 64; w++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) wo[k] += w < wid ? w3[k][w] : 0u;
+        off = pre_sum + wo[0] + x[0] - v[0];
+        r0 = wo[1] + x[1] - v[1];
+        r1 = wo[2] + x[2] - v[2];
+    }
     if (b < NB) {
         bin_offset[b] = off;
-        bin_cursor[(size_t)b * GSR_CPAD] = off;
+        bin_cursor[(size_t)b * GSR_CPAD] = off + c_rec;  // where the instances of incoherent workgroups start: behind the recorded ones
     }
     // work-ordered workgroup list: the classes in order (longest lists first, idle bins last), patch order (tiled_bin) inside each class
-    uint32_t blk_tot;
-    const uint32_t r0 = block_exscan(class_w0(cls), wsum, &blk_tot);
-    const uint32_t r1 = block_exscan(class_w1(cls), wsum, &blk_tot);
     if (wb >= 0) {
         const uint32_t pos = cls == 0 ? pre[0] + (r0 & 0xffffu)
                            : cls == 1 ? tot[0] + pre[1] + (r0 >> 16)
@@ -221,54 +253,110 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
     }
 }
 
-__global__ __launch_bounds__(GSR_BIN_THREADS) void k_scatter(int P, const uint32_t *__restrict__ row_range, int bx, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ hitmask,
-                                                            const uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_cursor, uint64_t *__restrict__ keys,
-                                                            const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
-                                                            const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid) {
+
+constexpr int SC_THREADS = 512;                          // threads of a scatter workgroup
+constexpr int SC_PER = GSR_BIN_THREADS / SC_THREADS;     // Gaussians per thread: a workgroup still owns the 1,024 Gaussians of one k_preprocess workgroup
+
+// (three workgroups per CU: 768 slots, so that the 586 workgroups of a 600 k-Gaussian view are all resident)
+__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scatter(int P, const uint32_t *__restrict__ row_range, int bx, const GsrSplat *__restrict__ splats, const uint4 *__restrict__ binrec,
+                                                       const uint32_t *__restrict__ wg_tab, const uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
+                                                       uint64_t *__restrict__ keys, const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
+                                                       const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid) {
+    __shared__ uint32_t s_cnt[GSR_BLOCK_TAB], s_base[GSR_BLOCK_TAB];
+    __shared__ int s_box[4];
+    // The kernel is a chain of memory round trips (round-5 counters: two thirds of its wave cycles are spent waiting): every load that depends on
+    // nothing but the launch is issued FIRST -- the Gaussians' records, the table header AND the table entries (unconditionally: entries beyond the
+    // box are never used), the slot run -- and only then examined.  What is left behind them is one gather of bin_offset.
+    const int i0 = blockIdx.x * GSR_BIN_THREADS;
+    const uint32_t *tab = wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS;
+    uint4 rec[SC_PER];
+#pragma unroll
+    for (int u = 0; u < SC_PER; u++) {
+        const int i = i0 + u * SC_THREADS + (int)threadIdx.x;
+        rec[u] = i < P ? binrec[i] : make_uint4(0u, 0u, 0u, 0u);  // (P = the launch capacity: rows behind a row-range view's last Gaussian hold neutral records)
+    }
+    constexpr int TPT = GSR_BLOCK_TAB / SC_THREADS;  // table entries per thread
+    uint32_t tent[TPT];
+#pragma unroll
+    for (int k = 0; k < TPT; k++) tent[k] = tab[4 + k * SC_THREADS + (int)threadIdx.x];
+    const int tab_bx0 = (int)tab[0], tab_by0 = (int)tab[1], tab_bw = (int)tab[2], tab_bh = (int)tab[3];
+    const uint32_t s_beg = inst_valid ? gpart[blockIdx.x] : 0u;
+    const uint32_t s_nxt = inst_valid ? ((blockIdx.x + 1 < gridDim.x) ? gpart[blockIdx.x + 1] : hdr->num_slots) : 0u;
     if (hdr->overflow) return;
-    const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     {
         uint32_t row0;
         gsr_view_rows(row_range, P, row0, P);  // with a row range P was only the capacity: records behind the view's last Gaussian were never written
     }
-    if ((int)(blockIdx.x * GSR_BIN_THREADS) >= P) return;  // workgroup entirely behind the view's last Gaussian (before any barrier: uniform)
+    if (i0 >= P) return;  // workgroup entirely behind the view's last Gaussian (before any barrier: uniform)
+    // bin_offset of the table entries that hold instances: the one dependent gather
+    const int area = tab_bw > 0 ? tab_bw * tab_bh : 0;
+    uint32_t toff[TPT];
+#pragma unroll
+    for (int k = 0; k < TPT; k++) {
+        const int t = k * SC_THREADS + (int)threadIdx.x;
+        toff[k] = 0u;
+        if (t < area && tent[k]) {
+            const int ty = t / tab_bw, tx = t - ty * tab_bw;
+            toff[k] = bin_offset[(tab_by0 + ty) * bx + tab_bx0 + tx];
+        }
+    }
     if (inst_valid) {
         // training: "no gradient record yet" for every slot of this workgroup's 1024 Gaussians (replaces a cap-byte memset).  Their slots are ONE
-        // contiguous run [gpart[blk], gpart[blk + 1]) -- cleared by the whole workgroup with 16-byte stores.  (Until round 4 every thread cleared
-        // its own Gaussian's run byte by byte: fine for the ~4-cell rects of trained scales, 100 strided byte stores per thread with scales at
-        // their clamp.)
-        const uint32_t s_beg = gpart[blockIdx.x], s_end = (blockIdx.x + 1 < gridDim.x) ? gpart[blockIdx.x + 1] : hdr->num_slots;
-        for (uint32_t k = (s_beg & ~15u) + (uint32_t)threadIdx.x * 16u; k < s_end; k += GSR_BIN_THREADS * 16u) {
-            if (k >= s_beg && k + 16u <= s_end) {
+        // contiguous run [gpart[blk], gpart[blk + 1]) -- cleared by the whole workgroup with 16-byte stores.
+        for (uint32_t k = (s_beg & ~15u) + (uint32_t)threadIdx.x * 16u; k < s_nxt; k += SC_THREADS * 16u) {
+            if (k >= s_beg && k + 16u <= s_nxt) {
                 *reinterpret_cast<uint4 *>(inst_valid + k) = make_uint4(0u, 0u, 0u, 0u);
             } else {
-                for (uint32_t b = (k > s_beg ? k : s_beg); b < k + 16u && b < s_end; b++) inst_valid[b] = 0;
+                for (uint32_t b = (k > s_beg ? k : s_beg); b < k + 16u && b < s_nxt; b++) inst_valid[b] = 0;
             }
         }
     }
-    uint32_t lo = 0, hi = 0, mask = 0;
-    uint64_t key = 0;
-    GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
-    if (i < P) {
-        mask = hitmask[i];  // the exact ellipse/bin tests of this Gaussian's rect, done once by k_preprocess
-        const float4 *rec = reinterpret_cast<const float4 *>(splats + i);
-        const float4 c = rec[2];
-        lo = __float_as_uint(c.z);
-        hi = __float_as_uint(c.w);
-        key = ((uint64_t)__float_as_uint(c.y) << 32) | (uint32_t)i;
-        if ((hi & 0xffff) > (lo & 0xffff)) {  // listed somewhere
-            const uint32_t area = ((hi & 0xffff) - (lo & 0xffff)) * ((hi >> 16) - (lo >> 16));
-            if (area > 32u) {  // rect too large for the cached mask: the predicate k_preprocess counted with (row intervals, or per cell for
-                               // ill-conditioned conics: gsr_masked_hit), re-evaluated from the record and the threshold k_preprocess left in the
-                               // mask word (never recomputed here: gsr_hit_from_threshold)
-                const float4 a = rec[0], b = rec[1];
-                hit = gsr_hit_from_threshold(a.x, a.y, a.z, a.w, b.x, __uint_as_float(mask));
+    uint32_t lo[SC_PER], hi[SC_PER], mask[SC_PER];
+    uint64_t key[SC_PER];
+    GsrHit hit[SC_PER];
+#pragma unroll
+    for (int u = 0; u < SC_PER; u++) {
+        const int i = i0 + u * SC_THREADS + (int)threadIdx.x;
+        const bool in = i < P;
+        lo[u] = in ? rec[u].y : 0u; hi[u] = in ? rec[u].z : 0u; mask[u] = in ? rec[u].w : 0u;
+        key[u] = ((uint64_t)rec[u].x << 32) | (uint32_t)i;
+        hit[u] = GsrHit{0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
+        if ((hi[u] & 0xffff) > (lo[u] & 0xffff)) {  // listed somewhere
+            const uint32_t ar = ((hi[u] & 0xffff) - (lo[u] & 0xffff)) * ((hi[u] >> 16) - (lo[u] >> 16));
+            if (ar > 32u) {  // rect too large for the cached mask: the predicate k_preprocess counted with (row intervals, or per cell for
+                             // ill-conditioned conics: gsr_masked_hit), re-evaluated from the splat record and the threshold k_preprocess left in the
+                             // mask word (never recomputed here: gsr_hit_from_threshold)
+                const float4 *sr = reinterpret_cast<const float4 *>(splats + i);
+                const float4 a = sr[0], b = sr[1];
+                hit[u] = gsr_hit_from_threshold(a.x, a.y, a.z, a.w, b.x, __uint_as_float(mask[u]));
             }
         }
     }
-    gsr_block_emit(
-        wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS, lo, hi, bx, gsr_masked_hit(hit, mask, lo, hi), [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); },
-        [&](uint32_t pos, uint32_t) { keys[pos] = key; });
+    if (tab_bw < 0) {
+        // not recorded: this workgroup's bins did not fit the table in the count pass (incoherent input).  Rebuild -- half the Gaussians per call, any
+        // split will do -- and reserve from the cursor the scan left behind the recorded instances of each bin.
+#pragma unroll
+        for (int u = 0; u < SC_PER; u++) {
+            const uint64_t k64 = key[u];
+            auto res = [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); };
+            gsr_block_bin<true, SC_THREADS>(s_cnt, s_base, s_box, lo[u], hi[u], bx, gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]), res, res,
+                                            [&](uint32_t pos, uint32_t) { keys[pos] = k64; });
+        }
+        return;
+    }
+    if (area == 0) return;  // nothing listed in this workgroup (uniform)
+    // slot of an instance = bin_offset[bin] + the base k_preprocess' count atomic returned for this workgroup + its rank here (LDS atomic)
+#pragma unroll
+    for (int k = 0; k < TPT; k++) {
+        const int t = k * SC_THREADS + (int)threadIdx.x;
+        if (t < area) { s_cnt[t] = 0u; s_base[t] = toff[k] + tent[k] - 1u; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SC_PER; u++) {
+        const uint64_t k64 = key[u];
+        gsr_block_emit_one(s_cnt, s_base, tab_bx0, tab_by0, tab_bw, lo[u], hi[u], gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]), [&](uint32_t pos, uint32_t) { keys[pos] = k64; });
+    }
 }
 
 // ascending compare-exchange on LDS / global arrays, virtual +inf padding beyond n (comparators with j >= n are no-ops)
@@ -457,17 +545,171 @@ __device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg,
     }
 }
 
+// ---- the same network on 32-bit COMPOSITE keys (round 5) ------------------------------------------------------------------------------
+// The 64-bit form above costs a lane exchange 4 cross-lane moves + v_min_f64 + v_max_f64 (half rate) + 4 selects per key; the sort kernel is
+// instruction-issue bound (round-4 counters).  Inside ONE bin the depths span a narrow range of float bit patterns (a body bin of config 2: a few
+// 10^5 of the 2^32), so (depth bits - smallest depth bits of the bin) fits the upper 32 - L bits of a word whose lower L bits hold the key's
+// POSITION in the unsorted segment (L = bits of n - 1 <= 10): one cross-lane move + v_min_u32 + v_max_u32 + one select per key, everything at full
+// rate.  Order of distinct depths = order of the composites, exactly.  Equal depths must come out in ascending Gaussian id (upstream's stable
+// order), which the position bits do not give: after the sort the ids of neighbours with equal depth fields are put in order by a short
+// odd-even transposition (sort_wave_regs32).  A list whose depth range does not fit is handed to the exact 64-bit sort instead.  Ids wait in
+// LDS (4 bytes per key) and are fetched by position once the order is known.
+template <int KPL, int KB, int ST>
+__device__ __forceinline__ void sort_stage32(uint32_t (&key)[KPL], int lane) {
+    constexpr int LOGK = KPL == 1 ? 0 : KPL == 2 ? 1 : KPL == 4 ? 2 : KPL == 8 ? 3 : 4;
+    constexpr uint32_t mask = ST == 0 ? ((1u << KB) - 1u) : (1u << (KB - 1 - ST));
+    constexpr uint32_t top = ST == 0 ? (1u << (KB - 1)) : mask;
+    constexpr uint32_t rmask = mask & (KPL - 1), lmask = mask >> LOGK;
+    if constexpr (lmask == 0) {
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const int r2 = r ^ (int)rmask;
+            if (r2 > r) {
+                const uint32_t a = key[r], b = key[r2];
+                key[r] = min(a, b);
+                key[r2] = max(a, b);
+            }
+        }
+    } else {
+        const bool lower = ((uint32_t)lane & (top >> LOGK)) == 0;
+        uint32_t other[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; r++) other[r] = lane_xor<lmask>(key[r ^ (int)rmask]);
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const uint32_t a = key[r], b = other[r];
+            key[r] = lower ? min(a, b) : max(a, b);
+        }
+    }
+}
+template <int KPL, int LOGN, int KB, int ST>
+__device__ __forceinline__ void sort_stages_from32(uint32_t (&key)[KPL], int lane) {
+    sort_stage32<KPL, KB, ST>(key, lane);
+    if constexpr (ST + 1 < KB) sort_stages_from32<KPL, LOGN, KB, ST + 1>(key, lane);
+    else if constexpr (KB < LOGN) sort_stages_from32<KPL, LOGN, KB + 1, 0>(key, lane);
+}
+
+// -> true: `out` holds the sorted ids; false: this list needs the 64-bit sort (depth range too wide for the composite)
+template <int KPL>
+__device__ __forceinline__ bool sort_wave_regs32(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, uint32_t *ids, int lane) {
+    constexpr int LOGK = KPL == 1 ? 0 : KPL == 2 ? 1 : KPL == 4 ? 2 : KPL == 8 ? 3 : 4;
+    constexpr int LOGN = LOGK + 6;
+    uint32_t key[KPL], lo[KPL];
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+    // (keys arrive unsorted: ANY assignment to the network's elements will do, so they are read COALESCED -- register r of lane l takes key
+    //  r * 64 + l -- and that index is the position the composite carries.  Round-5 counters: with lane-strided loads and stores this kernel issued
+    //  4x / 8x the memory requests its bytes need and spent 60 % of its wave cycles waiting for them; the network itself is a quarter of its time.)
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+        const uint64_t k = e < n ? seg[e] : 0ull;
+        key[r] = (uint32_t)(k >> 32);
+        lo[r] = (uint32_t)k;
+        if (e < n) { dmin = min(dmin, key[r]); dmax = max(dmax, key[r]); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, 64));
+    }
+    const uint32_t L = 32u - (uint32_t)__builtin_clz(n - 1u);  // n >= 2: 2^L >= n
+    if (!(dmax - dmin < (0xffffffffu >> L))) return false;     // (wave-uniform) the composite of a real key stays below the padding value
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+        if (e < n) ids[e] = lo[r];
+        key[r] = e < n ? (((key[r] - dmin) << L) | e) : 0xffffffffu;
+    }
+    sort_stages_from32<KPL, LOGN, 1, 0>(key, lane);
+    // ids by position (element e = lane * KPL + r now holds the e-th smallest composite)
+    sort_sync(true);  // the ids written above are read by other lanes of this wave
+    const uint32_t pm = (1u << L) - 1u;
+    uint32_t idr[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; r++) idr[r] = key[r] != 0xffffffffu ? ids[key[r] & pm] : 0xffffffffu;
+    // EQUAL DEPTHS must come out in ascending Gaussian id; the position bits ordered them arbitrarily.  Inside a bin the depths are so close that a
+    // few hundred keys usually hold a tie or two (config 2: ~40,000 distinct bit patterns per bin), so this is the normal case, not an exception:
+    // odd-even transposition of the IDS over neighbours with equal depth fields (the runs are 2-3 elements long), until a pass swaps nothing.
+    uint32_t eq = 0u;  // bit r: element (lane, r) and its successor in element order carry the same depth
+    {
+        const uint32_t next0 = (uint32_t)__shfl_down((int)key[0], 1, 64);
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const uint32_t nx = r + 1 < KPL ? key[r + 1 < KPL ? r + 1 : r] : (lane < 63 ? next0 : 0xffffffffu);
+            eq |= (nx != 0xffffffffu && (nx >> L) == (key[r] >> L)) ? (1u << r) : 0u;
+        }
+    }
+    if (__ballot(eq != 0u) != 0ull) {
+        // (the shuffle runs with EVERY lane active and the lane-0 case is selected afterwards: inside `lane > 0 ? shuffle : 0` lane 1 would read an
+        //  inactive lane 0 -- that was a real bug: duplicated ids at elements 15 / 16 of 11 of 20,331 lists of config 5)
+        const uint32_t eq_up = (uint32_t)__shfl_up((int)eq, 1, 64);
+        const uint32_t eq_prev = lane > 0 ? (eq_up >> (KPL - 1)) & 1u : 0u;  // my first element continues the previous lane's last run
+        for (;;) {
+            bool sw = false;
+#pragma unroll
+            for (int ph = 0; ph < 2; ph++) {  // pairs (e, e + 1) with e even, then with e odd; e = lane * KPL + r
+#pragma unroll
+                for (int r = 0; r + 1 < KPL; r++) {
+                    if ((r & 1) != ph) continue;  // (KPL is even here: the parity of e is the parity of r)
+                    const bool x = ((eq >> r) & 1u) && idr[r] > idr[r + 1];
+                    const uint32_t a = idr[r], b2 = idr[r + 1];
+                    idr[r] = x ? b2 : a;
+                    idr[r + 1] = x ? a : b2;
+                    sw |= x;
+                }
+                // the pair that straddles two lanes: (lane, KPL - 1) <-> (lane + 1, 0); its e is odd for KPL > 1, lane-parity dependent for KPL == 1
+                if (KPL > 1 ? ph == 1 : true) {
+                    const bool mine = KPL > 1 || (lane & 1) == ph;          // I hold the pair's first element in this phase
+                    const bool theirs = KPL > 1 || ((lane - 1) & 1) == ph;  // ... my predecessor does, and I hold the second
+                    const uint32_t nb = (uint32_t)__shfl_down((int)idr[0], 1, 64);        // successor lane's first id
+                    const uint32_t pa = (uint32_t)__shfl_up((int)idr[KPL - 1], 1, 64);    // predecessor lane's last id
+                    const bool x1 = mine && ((eq >> (KPL - 1)) & 1u) && idr[KPL - 1] > nb;
+                    const bool x0 = theirs && eq_prev && pa > idr[0];
+                    if (KPL > 1) {
+                        idr[KPL - 1] = x1 ? nb : idr[KPL - 1];
+                        idr[0] = x0 ? pa : idr[0];
+                    } else {
+                        idr[0] = x1 ? nb : (x0 ? pa : idr[0]);
+                    }
+                    sw |= x1;
+                }
+            }
+            if (__ballot(sw) == 0ull) break;
+        }
+    }
+    // the sorted ids leave through LDS once more: element lane * KPL + r sits in lane `lane`, a coalesced store wants element r * 64 + lane
+    sort_sync(true);  // (every lane has fetched its ids)
+#pragma unroll
+    for (int r = 0; r < KPL; r++) ids[(uint32_t)lane * KPL + r] = idr[r];
+    sort_sync(true);
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+        if (e < n) out[e] = ids[e];
+    }
+    return true;
+}
+
 // lists of 1..1024 keys (the common case: a body bin holds ~450): ONE WAVE per bin, keys in registers.
 __global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                   const GsrHeader *__restrict__ hdr) {
+    const uint32_t bin = wg_order[blockIdx.x];  // busy bins first (requested together with the header: one round trip, not two)
     if (hdr->overflow || blockIdx.x >= hdr->num_busy_wgs) return;
-    const uint32_t bin = wg_order[blockIdx.x];  // busy bins first
     const uint32_t off = bin_offset[bin], n = bin_offset[bin + 1] - off;
     if (n == 0 || n > 1024u) return;
     const uint64_t *seg = keys + off;
     uint32_t *out = point_list + off;
     const int lane = threadIdx.x;
+    __shared__ uint32_t ids[1024];
+    if (n == 1u) { if (lane == 0) out[0] = (uint32_t)seg[0]; return; }
+    bool done;
+    if (n <= 64u) done = sort_wave_regs32<1>(seg, n, out, ids, lane);
+    else if (n <= 128u) done = sort_wave_regs32<2>(seg, n, out, ids, lane);
+    else if (n <= 256u) done = sort_wave_regs32<4>(seg, n, out, ids, lane);
+    else if (n <= 512u) done = sort_wave_regs32<8>(seg, n, out, ids, lane);
+    else done = sort_wave_regs32<16>(seg, n, out, ids, lane);
+    if (done) return;  // (wave-uniform; otherwise: the exact 64-bit network below)
     if (n <= 64u) sort_wave_regs<1>(seg, n, out, lane);
     else if (n <= 128u) sort_wave_regs<2>(seg, n, out, lane);
     else if (n <= 256u) sort_wave_regs<4>(seg, n, out, lane);
@@ -657,7 +899,7 @@ __global__ __launch_bounds__(1024) void k_sort_large(int NB, const uint32_t *__r
 
 }  // namespace
 
-void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
+void gsr_launch_scan(const uint32_t *bin_count, const uint32_t *bin_count_fb, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
                      int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
                      uint32_t order_hint, hipStream_t s) {
     const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB: ragged patches at the grid edge)
@@ -666,20 +908,20 @@ void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *
     //  outputs, but 40.8 us against the fused form's 14.6: sixteen dependent rounds of patch-order index arithmetic and gathers on one CU cost far
     //  more than the release / acquire round trip they avoid.  Removed; profiles/r03_issue_probes.md section 4.)
     if (nblocks <= GSR_SCAN_FUSE_MAX) {
-        hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap,
+        hipLaunchKernelGGL(k_scan_b<true>, dim3(nblocks), dim3(SB), 0, s, bin_count, bin_count_fb, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap,
                            hdr, gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0, order_hint);
         return;
     }
-    hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, NB, bx, by, order_hint);
-    hipLaunchKernelGGL(k_scan_b<false>, dim3(nblocks), dim3(SB), 0, s, bin_count, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap, hdr,
+    hipLaunchKernelGGL(k_scan_a, dim3(nblocks), dim3(SB), 0, s, bin_count, bin_count_fb, scan_part, NB, bx, by, order_hint);
+    hipLaunchKernelGGL(k_scan_b<false>, dim3(nblocks), dim3(SB), 0, s, bin_count, bin_count_fb, scan_part, bin_offset, bin_cursor, wg_order, NB, bx, by, nblocks, cap, hdr,
                        gpart, n_gblocks, host_hdr, host_seq, no_large_sort ? 1 : 0, order_hint);
 }
 
-void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s) {
+void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_offset,
+                        uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(GSR_BIN_THREADS), 0, s, P, row_range, bx, splats, hitmask, wg_tab, bin_cursor, keys, hdr,
-                       goff, gpart, inst_valid);
+    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(SC_THREADS), 0, s, P, row_range, bx, splats, binrec, wg_tab, bin_offset, bin_cursor, keys,
+                       hdr, goff, gpart, inst_valid);
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,

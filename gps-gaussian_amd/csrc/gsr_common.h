@@ -9,14 +9,15 @@
 //
 // Data layout in HBM (all carved from ONE caller-owned workspace, 256-byte aligned sections):
 //   header         GsrHeader (64 B)                      R needed, overflow flag, stats
-//   bin_count[NB], bin_cursor[NB]                        u32 per bin (GSR_CPAD = stride in words; with the workgroup-aggregated
+//   bin_count[NB], bin_count_fb[NB], bin_cursor[NB]      u32 per bin (GSR_CPAD = stride in words; with the workgroup-aggregated
 //                                                        binning a bin receives only a handful of atomics, so dense counters
 //                                                        are as fast as one-per-128-byte-line ones and the scan reads them coalesced)
 //   bin_offset[NB+1], wg_order[NB/4], scan_part[...]     dense exclusive offsets; work-ordered workgroup list (busy first)
 //   splats[P]      48-byte records {x,y,A,B | C,op,r,g | b,depth,binrect_lo,binrect_hi}: everything the compositing
 //                  kernels gather per instance sits in one record (1-2 cache lines per gather instead of 3 arrays)
-//   hitmask[P]     u32: bit k = the k-th cell (row-major) of the Gaussian's bin rect passed the exact ellipse/bin test, computed once
-//                  by k_preprocess and reused by k_scatter (rects of more than 32 cells store ~0 and are re-tested there)
+//   binrec[P]      16 bytes {depth bits, bin rect lo, hi, mask}: all k_scatter reads of a Gaussian.  mask bit k = the k-th cell (row-major) of its bin
+//                  rect passed the exact ellipse/bin test, computed once by k_preprocess (rects of more than 32 cells carry the bits of the test's
+//                  threshold instead and are re-tested by k_scatter from the splat record)
 //   wg_tab[P/1024][4+2048]  per binning workgroup: bin box + per-bin instance counts of its 1024 Gaussians, recorded by k_preprocess
 //                  and consumed by k_scatter (which then skips the box reduction, the table clearing and the counting loop)
 //   keys[cap]      u64 (depth_bits << 32 | gaussian id), binned, then sorted in LDS per bin
@@ -65,7 +66,7 @@ struct __attribute__((aligned(32))) GsrGradAcc {
 static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte sector");
 
 struct GsrLayout {
-    size_t header, bin_count, bin_offset, bin_cursor, wg_order, scan_part, splats, hitmask, wg_tab, keys, point_list, final_T, n_contrib;
+    size_t header, bin_count, bin_count_fb, bin_offset, bin_cursor, wg_order, scan_part, splats, binrec, wg_tab, keys, point_list, final_T, n_contrib;
     size_t total_fwd;  // bytes a forward-only workspace needs
     size_t goff, gscan_part, inst_valid, inst_dop, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
@@ -94,14 +95,15 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     size_t o = 0;
     const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.NB > 0 ? L.NB : 1), c = (size_t)(cap > 0 ? cap : 1);
     const size_t npix = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
-    L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + scan_part + bin_count are zeroed by ONE memset
-    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 32);  // two uint4 per scan block
+    L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + scan_part + bin_count + bin_count_fb are zeroed by ONE memset
+    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 32);  // two 64-bit words per scan block (+ padding)
     L.bin_count = o;  o = gsr_align_up(o + t * 4 * GSR_CPAD);
+    L.bin_count_fb = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);  // instances counted by workgroups whose bins do not fit the LDS table (see gsr_block_bin)
     L.bin_offset = o; o = gsr_align_up(o + (t + 1) * 4);
     L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
-    L.hitmask = o;    o = gsr_align_up(o + p * 4);
+    L.binrec = o;     o = gsr_align_up(o + p * 16);
     L.wg_tab = o;     o = gsr_align_up(o + ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
     L.keys = o;       o = gsr_align_up(o + c * 8);
     L.point_list = o; o = gsr_align_up(o + c * 4);
@@ -136,11 +138,12 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
 struct GsrHit {
     float x, y, A, B, C, thr, rA, rC;
 };
-__device__ __forceinline__ GsrHit gsr_hit_setup(float x, float y, float A, float B, float C, float op) {
+// tau = logf(255 op), which the caller has computed already (a second logf() per Gaussian was ~25 vector instructions of a VALU-bound kernel)
+__device__ __forceinline__ GsrHit gsr_hit_setup(float x, float y, float A, float B, float C, float tau) {
     _Pragma("clang fp contract(off)")
     GsrHit h;
     h.x = x; h.y = y; h.A = A; h.B = B; h.C = C;
-    h.thr = 2.f * logf(255.f * op) * 1.002f + 0.02f;
+    h.thr = 2.f * tau * 1.002f + 0.02f;
     h.rA = 1.f / A;
     h.rC = 1.f / C;
     return h;
@@ -265,18 +268,26 @@ __device__ __forceinline__ GsrMaskedHit gsr_masked_hit(const GsrHit &h, uint32_t
     return m;
 }
 
-// `tab` (count pass only, may be NULL): this workgroup's table is also written to global memory as {bx0, by0, bw, bh, counts[bw*bh]}
-// (bw = -1: not recorded -- incoherent input) so that the scatter pass of the SAME 1024 Gaussians can start from it
-// (gsr_block_emit) instead of rebuilding it.
+// ---- the two binning passes of a workgroup of (up to) 1,024 consecutive Gaussians ----------------------------------------------------------
+// COUNT pass (k_preprocess, gsr_block_bin<false>): histogram the workgroup's instances into the LDS table over its bin box, then ONE returning
+// global atomic per touched bin: bin_count[bin] += count.  The value it returns is this workgroup's BASE inside the bin's list; it is recorded
+// in `tab` = {bx0, by0, bw, bh, base + 1 per table entry (0: no instance)} for the scatter pass of the same Gaussians.
+// SCATTER pass (k_scatter, gsr_block_emit_*): slot = bin_offset[bin] + recorded base + rank inside the workgroup (LDS atomic) -- no global atomic,
+// no counting loop, no box reduction (round 5; until then the scatter pass reserved its slots with a second returning atomic per bin).
+// INCOHERENT input -- a bin box that does not fit the table (normal case: the ONE workgroup whose 1,024 Gaussians straddle the end of the first
+// source view and the start of the second: a box as tall as the subject) -- is counted band by band into a SECOND counter array
+// (reserve_fb -> bin_count_fb) and not recorded (tab[2] = -1); the scan places those instances BEHIND the recorded ones of their bin
+// (bin_cursor = offset + recorded count) and the scatter pass of that workgroup rebuilds its tables and reserves from that cursor
+// (gsr_block_bin<true>).  Both passes must take identical (Gaussian, bin) decisions: `hit`.
 #define GSR_WG_TAB_WORDS (4 + GSR_BLOCK_TAB)
-template <bool EMIT, typename Hit, typename Reserve, typename Emit>
-__device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, Hit hit, Reserve reserve, Emit emit, uint32_t *tab = nullptr) {
-    __shared__ int s_box[4];
-    __shared__ uint32_t s_cnt[GSR_BLOCK_TAB];
-    __shared__ uint32_t s_base[EMIT ? GSR_BLOCK_TAB : 1];
+// NT = threads of the workgroup (one Gaussian per thread and call); s_cnt / s_base: GSR_BLOCK_TAB words of LDS each (s_base: EMIT only), s_box: 4.
+template <bool EMIT, int NT, typename Hit, typename Reserve, typename ReserveFb, typename Emit>
+__device__ __forceinline__ void gsr_block_bin(uint32_t *s_cnt, uint32_t *s_base, int *s_box, uint32_t lo, uint32_t hi, int bx, Hit hit, Reserve reserve,
+                                              ReserveFb reserve_fb, Emit emit, uint32_t *tab = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
     const bool has = (x1 > x0) && (y1 > y0);
+    __syncthreads();  // (a previous call's tables are done with)
     if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
     int mnx = has ? x0 : 0x7fffffff, mny = has ? y0 : 0x7fffffff, mxx = has ? x1 : -1, mxy = has ? y1 : -1;
 #pragma unroll
@@ -297,18 +308,15 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
     const int area = bw * bh;
     if (tab && tid < 4) tab[tid] = area > GSR_BLOCK_TAB ? 0xffffffffu : (uint32_t)(tid == 0 ? bx0 : tid == 1 ? by0 : tid == 2 ? bw : bh);
     if (area > GSR_BLOCK_TAB && bw <= GSR_BLOCK_TAB) {
-        // The workgroup's bins do not fit the table (uniform branch).  Normal case of this branch: the ONE workgroup whose 1024 Gaussians straddle
-        // the end of the first source view and the start of the second (pixels from the bottom and from the top of the image: a box as tall as the
-        // subject).  The table is then applied to BANDS of bin rows, one after the other.  (Until round 4 such a workgroup fell back to one GLOBAL
-        // atomic per instance: invisible with ~5 instances per Gaussian, but with scales at their clamp it is 70 dependent global atomics per thread
-        // in one workgroup -- ~100 us during which the rest of the chip had long finished: k_preprocess 142 us and k_scatter 183 us at R = 3e7,
-        // of which the per-cell work was 10 us, measured with the GSR_ABL_COUNT_* probes.)
+        // The workgroup's bins do not fit the table (uniform branch): the table is applied to BANDS of bin rows, one after the other.  (Until round 4
+        // such a workgroup fell back to one GLOBAL atomic per instance: invisible with ~5 instances per Gaussian, but with scales at their clamp it
+        // is 70 dependent global atomics per thread in one workgroup -- ~100 us during which the rest of the chip had long finished.)
         const int band_h = GSR_BLOCK_TAB / bw;  // >= 1 bin rows per pass
         for (int yb = by0; yb < by0 + bh; yb += band_h) {
             const int yb1 = min(yb + band_h, by0 + bh), barea = (yb1 - yb) * bw;
             const int ya = max(y0, yb), yz = min(y1, yb1);
             __syncthreads();  // the previous band's table is done with
-            for (int t = tid; t < barea; t += GSR_BIN_THREADS) s_cnt[t] = 0u;
+            for (int t = tid; t < barea; t += NT) s_cnt[t] = 0u;
             __syncthreads();
             if (has)
                 for (int y = ya; y < yz; y++) {
@@ -318,11 +326,11 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
                         if (hit(x, y)) atomicAdd(&s_cnt[(y - yb) * bw + (x - bx0)], 1u);
                 }
             __syncthreads();
-            for (int t = tid; t < barea; t += GSR_BIN_THREADS) {
+            for (int t = tid; t < barea; t += NT) {
                 const uint32_t c = s_cnt[t];
                 if (c) {
                     const int ty = t / bw, tx = t - ty * bw;
-                    const uint32_t base = reserve((yb + ty) * bx + bx0 + tx, c);
+                    const uint32_t base = reserve_fb((yb + ty) * bx + bx0 + tx, c);
                     if (EMIT) { s_base[t] = base; s_cnt[t] = 0u; }
                 }
             }
@@ -349,13 +357,13 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
                 hit.span(y, xa, xb);
                 for (int x = xa; x < xb; x++) {
                     if (!hit(x, y)) continue;
-                    const uint32_t pos = reserve(y * bx + x, 1u);
+                    const uint32_t pos = reserve_fb(y * bx + x, 1u);
                     if (EMIT) emit(pos, (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
                 }
             }
         return;
     }
-    for (int t = tid; t < area; t += GSR_BIN_THREADS) s_cnt[t] = 0u;
+    for (int t = tid; t < area; t += NT) s_cnt[t] = 0u;
     __syncthreads();
     if (has)
         for (int y = y0; y < y1; y++) {
@@ -365,14 +373,15 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
                 if (hit(x, y)) atomicAdd(&s_cnt[(y - by0) * bw + (x - bx0)], 1u);
         }
     __syncthreads();
-    for (int t = tid; t < area; t += GSR_BIN_THREADS) {
+    for (int t = tid; t < area; t += NT) {
         const uint32_t c = s_cnt[t];
-        if (tab) tab[4 + t] = c;
+        uint32_t base = 0u;
         if (c) {
             const int ty = t / bw, tx = t - ty * bw;
-            const uint32_t base = reserve((by0 + ty) * bx + bx0 + tx, c);
+            base = reserve((by0 + ty) * bx + bx0 + tx, c);
             if (EMIT) { s_base[t] = base; s_cnt[t] = 0u; }
         }
+        if (tab) tab[4 + t] = c ? base + 1u : 0u;  // this workgroup's base inside the bin's list, for the scatter pass
     }
     if (!EMIT) return;
     __syncthreads();
@@ -387,28 +396,9 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t lo, uint32_t hi, int bx, 
             }
         }
 }
-// Scatter pass from the recorded table: no bounding-box reduction, no table clearing, no counting loop -- one barrier.
-template <typename Hit, typename Reserve, typename Emit>
-__device__ __forceinline__ void gsr_block_emit(const uint32_t *tab, uint32_t lo, uint32_t hi, int bx, Hit hit, Reserve reserve, Emit emit) {
-    const int bw = (int)tab[2];
-    if (bw < 0) {  // not recorded (incoherent input): rebuild
-        gsr_block_bin<true>(lo, hi, bx, hit, reserve, emit);
-        return;
-    }
-    __shared__ uint32_t e_cnt[GSR_BLOCK_TAB];
-    __shared__ uint32_t e_base[GSR_BLOCK_TAB];
-    const int tid = threadIdx.x;
-    const int bx0 = (int)tab[0], by0 = (int)tab[1], area = bw * (int)tab[3];
-    if (area == 0) return;  // nothing listed in this workgroup (uniform)
-    for (int t = tid; t < area; t += GSR_BIN_THREADS) {
-        const uint32_t c = tab[4 + t];
-        e_cnt[t] = 0u;
-        if (c) {
-            const int ty = t / bw, tx = t - ty * bw;
-            e_base[t] = reserve((by0 + ty) * bx + bx0 + tx, c);
-        }
-    }
-    __syncthreads();
+// Scatter pass from the recorded table (k_scatter sets the tables up itself): per Gaussian, rank inside the workgroup by LDS atomic, then emit.
+template <typename Hit, typename Emit>
+__device__ __forceinline__ void gsr_block_emit_one(uint32_t *e_cnt, const uint32_t *e_base, int bx0, int by0, int bw, uint32_t lo, uint32_t hi, Hit hit, Emit emit) {
     const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
     if ((x1 > x0) && (y1 > y0))
         for (int y = y0; y < y1; y++) {
@@ -439,13 +429,13 @@ struct GsrFwdParams {
     uint32_t sh_degree, sh_coeffs;
 };
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binrec, uint32_t *wg_tab, uint32_t *bin_count, uint32_t *bin_count_fb, GsrHeader *hdr,
                            hipStream_t s);
-void gsr_launch_scan(const uint32_t *bin_count, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx, int by,
-                     int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort,
-                     uint32_t order_hint, hipStream_t s);
-void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint32_t *hitmask, const uint32_t *wg_tab, uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr,
-                        const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s);
+void gsr_launch_scan(const uint32_t *bin_count, const uint32_t *bin_count_fb, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx,
+                     int by, int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort, uint32_t order_hint,
+                     hipStream_t s);
+void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_offset,
+                        uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s);
 void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,

@@ -185,11 +185,12 @@ struct CountHit {
 // APPEAR = true: SH colours (q.shs) and / or precomputed 3D covariances (q.cov3D_precomp) -- its own instantiation, so that the common one carries
 // neither the branches nor the registers of these inputs.
 template <bool APPEAR>
-__global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint32_t *__restrict__ hitmask,
-                                                               uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_count,
+__global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint4 *__restrict__ binrec,
+                                                               uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_count_fb,
                                                                GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
     uint32_t rlo = 0, rhi = 0;
+    float depth_out = 0.f;
     GsrHit hit = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
     // the view's Gaussians: rows [row0, row0 + nP) of the input / output arrays (row0 = 0, nP = P without a row range); everything
     // inside the workspace is indexed by i, the Gaussian's number inside the view
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     if (i == 0) {
         const uint32_t m = q.row_range ? q.row_range[1] - q.row_range[0] : (uint32_t)q.P;
         hdr->num_points = m;
-        if (m > (uint32_t)q.P) hdr->row_overflow = 1u;  // more rows than the capacity the call was sized for: k_scan_b reports an overflow
+        if (m > (uint32_t)q.P) hdr->row_overflow = 1u;  // more rows than the capacity the call was sized for: k_scan reports an overflow
     }
     if ((int)(blockIdx.x * GSR_BIN_THREADS) >= nP && nP < q.P) {
         // a row-range view is launched for its CAPACITY: a workgroup entirely behind the view's last Gaussian only leaves the neutral
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
             if (i < q.P) q.goff[i] = 0u;
             if (threadIdx.x == 0) q.gpart[blockIdx.x] = 0u;
         }
-        if (i < q.P) hitmask[i] = 0u;
+        if (i < q.P) binrec[i] = make_uint4(0u, 0u, 0u, 0u);
         if (threadIdx.x < 4) wg_tab[(size_t)blockIdx.x * GSR_WG_TAB_WORDS + threadIdx.x] = 0u;
         return;
     }
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
                     if (b1x > b0x && b1y > b0y) {
                         rlo = (uint32_t)b0x | ((uint32_t)b0y << 16);
                         rhi = (uint32_t)b1x | ((uint32_t)b1y << 16);
-                        hit = gsr_hit_setup(px, py, c * det_inv, -b * det_inv, a * det_inv, op);  // from the STORED record values
+                        hit = gsr_hit_setup(px, py, c * det_inv, -b * det_inv, a * det_inv, tau);  // from the STORED record values
                     }
                 }
             }
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     dst[0] = o0;
     dst[1] = o1;
     dst[2] = make_float4(o2x, o2y, __uint_as_float(rlo), __uint_as_float(rhi));
+    depth_out = o2y;
     q.radii[r] = radius;
     }
     if (q.goff) {  // training workspace: the slot prefix the backward needs (gradient-record slots = bin-rect cells) falls out here
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
             tot += v;
         }
         if (i < q.P) q.goff[i] = woff + x - area;  // prefix inside this block of 1024 Gaussians
-        if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan_b turns these into the prefix of the blocks
+        if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan turns these into the prefix of the blocks
     }
     // the exact ellipse/bin test of every cell of the rect is evaluated ONCE, here; the outcomes are kept as a bit mask
     // (cell k = row-major index inside the rect) that k_scatter reuses instead of re-testing every cell twice
@@ -340,15 +342,26 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
     CountHit ch;
     ch.h = hit; ch.mask = &mask;
     ch.x0 = rlo & 0xffff; ch.y0 = rlo >> 16; ch.w = (int)(rhi & 0xffff) - ch.x0;
-    ch.rs = gsr_rows_setup(hit);
-    ch.rows = ch.rs.ok && ch.w * ((int)(rhi >> 16) - ch.y0) > 32;  // the rule of gsr_masked_hit(): k_scatter decides with the same numbers
-    gsr_block_bin<false>(
-        rlo, rhi, q.bx, ch,
-        [&](int bin, uint32_t cnt) { atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t, uint32_t) {},
-        wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS);
+    const bool big_rect = ch.w * ((int)(rhi >> 16) - ch.y0) > 32;
+    ch.rs.ok = 0;
+    if (big_rect) ch.rs = gsr_rows_setup(hit);  // (a division and a square root nobody needs for the ~4-cell rects of trained scales)
+    ch.rows = ch.rs.ok && big_rect;  // the rule of gsr_masked_hit(): k_scatter decides with the same numbers
+    {
+        __shared__ uint32_t s_cnt[GSR_BLOCK_TAB];
+        __shared__ int s_box[4];
+        gsr_block_bin<false, GSR_BIN_THREADS>(
+            s_cnt, nullptr, s_box, rlo, rhi, q.bx, ch,
+            // the RETURNED value is this workgroup's base inside the bin's list: recorded in wg_tab for k_scatter (which then needs no atomic of its own)
+            [&](int bin, uint32_t cnt) { return atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt); },
+            // a workgroup whose bins do not fit the table counts into the second array: its instances are placed behind the recorded ones
+            [&](int bin, uint32_t cnt) { atomicAdd(&bin_count_fb[(size_t)bin * GSR_CPAD], cnt); return 0u; }, [](uint32_t, uint32_t) {},
+            wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS);
+    }
     // rects of more than 32 cells are not cached: k_scatter re-tests their cells, with THIS threshold (see gsr_hit_from_threshold)
     if ((int)((rhi & 0xffff) - (rlo & 0xffff)) * (int)((rhi >> 16) - (rlo >> 16)) > 32) mask = __float_as_uint(hit.thr);
-    if (i < q.P) hitmask[i] = mask;
+    // everything k_scatter needs of a Gaussian in ONE aligned 16-byte record {depth bits, bin rect, mask}: it used to gather 16 of the 48 bytes of
+    // the splat record (a strided read that pulled most of the 29 MB array) + the mask word
+    if (i < q.P) binrec[i] = make_uint4(__float_as_uint(depth_out), rlo, rhi, mask);
 }
 
 template <bool APPEAR>  // as k_preprocess: true = SH colours and / or precomputed covariances among the inputs
@@ -612,12 +625,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
 
 }  // namespace
 
-void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint32_t *hitmask, uint32_t *wg_tab, uint32_t *bin_count, GsrHeader *hdr,
+void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binrec, uint32_t *wg_tab, uint32_t *bin_count, uint32_t *bin_count_fb, GsrHeader *hdr,
                            hipStream_t s) {
     if (p.P <= 0) return;
     const dim3 grid((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), block(GSR_BIN_THREADS);
-    if (p.shs || p.cov3D_precomp) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, p, splats, hitmask, wg_tab, bin_count, hdr);
-    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, p, splats, hitmask, wg_tab, bin_count, hdr);
+    if (p.shs || p.cov3D_precomp) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, p, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
+    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, p, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,

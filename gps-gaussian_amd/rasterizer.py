@@ -166,7 +166,7 @@ def _drain_pending(st, block=False):
                 keep.extend(pending[i + 1:])  # (their slots are looked at -- and released -- by the next call)
                 raise RuntimeError(
                     "gps_gaussian_amd: a previous rasteriser call (GPSGS_CHECK=deferred) was not rendered: it needed %d (Gaussian, bin) instances / "
-                    "gradient slots (its workspace had room for fewer) and its longest bin list was %d entries. Capacity has been raised; re-run, "
+                    "gradient slots -- more than the capacity of its workspace -- and its longest bin list was %d entries. The capacity has been raised; re-run, "
                     "or use GPSGS_CHECK=sync." % (need, longest if ent[0] == "note" else (int(hdr[1]) >> 32) & 0xffffffff))
     finally:
         with _lock:
