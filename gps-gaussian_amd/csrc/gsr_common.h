@@ -79,42 +79,6 @@ struct GsrLayout {
 
 static inline size_t gsr_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct __attribute__((aligned(16))) GsrSplat {
-    float x, y, A, B;        // pixel-space mean, conic xx, xy
-    float C, op, r, g;       // conic yy, opacity, colour
-    float b, depth;          // colour, view-space depth
-    uint32_t bin_lo, bin_hi; // bx0 | by0<<16 , bx1 | by1<<16  (bin units, exclusive upper; empty = not listed anywhere)
-};
-static_assert(sizeof(GsrSplat) == 48, "splat record must be 48 bytes");
-
-struct __attribute__((aligned(32))) GsrGradAcc {
-    float dr, dg, db, dmx;    // dL/dcolor, dL/dmean2D.x (NDC-scaled)
-    float dmy, cxx, cxy, cyy; // dL/dmean2D.y, dL/dconic (xy holds HALF the true off-diagonal gradient, like upstream)
-};                            // dL/dopacity lives in inst_dop[]
-static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte sector");
-
-struct GsrLayout {
-    size_t header, bin_count, bin_count_fb, bin_offset, bin_cursor, wg_order, scan_part, splats, binrec, wg_tab, keys, point_list, final_T, n_contrib;
-    size_t total_fwd;  // bytes a forward-only workspace needs
-    size_t goff, gscan_part, inst_valid, inst_dop, inst_grad, total;
-    int gx, gy;   // 16x16 tile grid (upstream semantics)
-    int bx, by;   // bin grid: bx = ceil(W/8) rounded up to a multiple of 4, by = ceil(H/8)
-    int bx_real;  // ceil(W/8)
-    int NB;       // bx * by
-    int NWG;      // NB / GSR_BINS_PER_WG compositing workgroups
-    int NSB;      // scan blocks = ceil(max(NB, indices of the patch work order) / GSR_SCAN_BLOCK)
-};
-
-static inline size_t gsr_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
-// development knob: GPSGS_DEBUG_TAIL_PAD=<bytes> of padding in front of the backward tail of the workspace (does the placement of the gradient-record
-// sections relative to each other / to the HBM channels matter?); 0 / unset in normal use
-#include <stdlib.h>
-static inline size_t gsr_debug_tail_pad() {
-    static long v = -1;
-    if (v < 0) { const char *e = getenv("GPSGS_DEBUG_TAIL_PAD"); v = e ? atol(e) : 0; if (v < 0) v = 0; }
-    return (size_t)v;
-}
-
 static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     GsrLayout L;
     L.gx = (W + GSR_TILE - 1) / GSR_TILE;
