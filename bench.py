@@ -5,7 +5,10 @@
 
 Metric (BASELINE.json): novel views/s at 1024x1024 with ~600k pixel-Gaussians.  One "step" = one pass of the render
 hot path over one synthetic view of BASELINE config 2: HIP rasteriser forward + backward (1024x1024, P = 600,000
-Gaussians resident in HBM before the timed region).  Forward-only throughput is reported next to it.
+Gaussians resident in HBM before the timed region), called the way the reference calls it -- GaussianRasterizer(raster_settings)(means3D=..., ...)
++ image.backward(), /root/reference/gaussian_renderer/__init__.py:51-62 -- one view at a time with the exact capacity check: `value`.
+What a caller that owns its buffers gets from the C-ABI sessions (one view at a time, and six views in flight on six streams) is reported
+next to it (`session`), as are forward-only throughput, the stage-2 gradient set and the other BASELINE configurations.
 N > 1: every rank renders its own views (independent units, no data-path collective) -> weak scaling; the only
 collectives are the timing barrier and the MAX-over-ranks reduction of the elapsed time.
 
@@ -28,6 +31,36 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_PEAK_TLANEOPS = 78.6   # 157.3 TFLOP/s fp32 vector = 78.6 T FMA lane-ops/s
+
+
+def stage_bytes(P, R, NB, npix, n_slots=None, n_rec=None):
+    """ALGORITHMIC bytes per launch of every stage (SURVEY.md section 8d convention: each input read once, each intermediate
+    written once and read once, each output written once).  R = measured (Gaussian, 8x8-bin) instances, NB = bins, n_slots = gradient-record slots
+    (bin-rect cells of all Gaussians), n_rec = slots the compositing backward wrote a record into (<= R).  Unknown counts fall back to R.
+      preprocess      44 P in + 48 P splat record + 16 P bin record + 4 P radii + 8 P slot prefix       = 120 P
+      scan            8 NB counters in (two arrays) + 8 NB offsets / cursors + 4 NB work order            = 20 NB
+      scatter         16 P bin records + 8 R keys + n_slots flag bytes cleared                            = 16 P + 8 R + n_slots
+      sort            8 R keys in + 4 R ids out + 8 NB ranges                                              = 12 R + 8 NB
+      composite_fwd   4 R ids + 36 R splat record fields + 8 NB + 12 Npix image + 8 Npix state            = 40 R + 8 NB + 20 Npix
+      composite_bwd   as the forward's reads + 12 Npix dL/dpix + 8 Npix state, + 37 B per record written  = 40 R + 8 NB + 20 Npix + 37 n_rec
+      preprocess_bwd  n_slots flags + 36 n_rec records + 40 P inputs + 8 P slot prefix + 68 P gradients   = n_slots + 36 n_rec + 116 P"""
+    n_slots = R if n_slots is None else n_slots
+    n_rec = R if n_rec is None else n_rec
+    return {"preprocess": 120 * P, "scan": 20 * NB, "scatter": 16 * P + 8 * R + n_slots, "sort": 12 * R + 8 * NB, "composite_fwd": 40 * R + 8 * NB + 20 * npix,
+            "composite_bwd": 40 * R + 8 * NB + 20 * npix + 37 * n_rec, "preprocess_bwd": n_slots + 36 * n_rec + 116 * P}
+
+
+def counter_traffic(fname, P, W, H, R):
+    """Per-stage HBM traffic from the separate rocprofv3 --pmc passes (tools/prof_r05.sh -> profiles/<fname>, which records the workload it was
+    measured on); {} unless THIS run is that workload (same P, size, R within 1 %)."""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        wl = pj.get("workload", {})
+        if wl.get("P") == P and wl.get("W") == W and wl.get("H") == H and abs(wl.get("R", -1) - R) <= 0.01 * R:
+            return pj
+    except Exception:  # noqa: BLE001
+        pass
+    return {}
 
 
 def stage2_leg(args, sample, dev, rank, local_rank, world, D, timed, batch=4, steps=10):
@@ -163,8 +196,18 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         P = out["P"]
         NB = (((render_res + 7) // 8 + 3) // 4 * 4) * ((render_res + 7) // 8)
         npix = render_res * render_res
-        alg = {"preprocess": 116 * P, "scan": 8 * NB, "scatter": 24 * P + 12 * R, "sort": 12 * R + 8 * NB, "composite_fwd": 40 * R + 8 * NB + 20 * npix,
-               "composite_bwd": 40 * R + 8 * NB + 20 * npix + 44 * P, "preprocess_bwd": 212 * P}
+        # gradient records of this view: slots (one flag byte each, read by k_preprocess_bwd) and slots that hold a 36-byte record (written by the
+        # compositing backward, read back by k_preprocess_bwd) -- counted on the device after a backward (212 P under-counts a
+        # regime with ~100 slots per Gaussian)
+        run("train", 1, 1)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        sess0 = lanes[0]["train"]
+        _capi.check(_capi.lib().gsr_debug_count_records(sess0.ws.data_ptr(), P, render_res, render_res, sess0.cap, cnt.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream), "gsr_debug_count_records")
+        torch.cuda.synchronize(dev)
+        n_rec, n_slots = int(cnt[0]), int(cnt[1])
+        out["gradient_records"] = {"slots": n_slots, "written": n_rec}
+        alg = stage_bytes(P, R, NB, npix, n_slots, n_rec)
         RZ.set_stage_timing(True)
         run("train", 1, 3)
         torch.cuda.synchronize(dev)
@@ -173,10 +216,14 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         st = _capi.timing_read()
         RZ.set_stage_timing(False)
         tab = {}
+        traffic = counter_traffic("pmc_traffic_regime.json", P, render_res, render_res, R)
         for k, (ms, n) in st.items():
             if n:
                 us = ms / n * 1e3
                 tab[k] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": alg[k], "hbm_frac": round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+                tr = traffic.get(k, {}).get("hbm_bytes_per_launch")
+                if tr:
+                    tab[k].update(counter_bytes=tr, counter_gbs=round(tr / (us * 1e-6) / 1e9, 1), traffic_ratio=round(tr / alg[k], 3))
         out["stages_one_view_in_flight"] = tab
         out["stages_sum_us"] = round(sum(v["avg_us"] for v in tab.values()), 1)
         out["longest_bin_list"] = int(RZ._dev_state(dev).get("longest", 0))
@@ -503,10 +550,10 @@ def main():
                     stages[k_] = (ms_, n_)
     dom_stage = max(stages, key=lambda k: (stages[k][0] / stages[k][1]) if stages[k][1] else 0.0)
 
-    # ---- the timed region.  Only the dominant kernel keeps its hipEvent bracket (on the launch stream), so that the measurement does
-    # not perturb the pipeline it measures.  After the switch to that final mode >= 10 untimed steps run before anything is timed.
-    # Then REPEATS blocks of EXACTLY --steps steps each are timed (barrier + synchronize on both sides, MAX over ranks); `value`,
-    # `ms_per_step` are those of the MEDIAN block (all blocks are listed in `repeats_ms_per_step`). ------------------------------------
+    # ---- the session regions (secondary; `value` is measured further down, through the reference's plugin API).  Only the dominant kernel keeps
+    # its hipEvent bracket (on the launch stream), so that the measurement does not perturb the pipeline it measures.  After the switch to that
+    # mode >= 10 untimed steps run before anything is timed.  Then REPEATS blocks of EXACTLY --steps steps with F views in flight are timed
+    # (barrier + synchronize on both sides, MAX over ranks): `session.views_in_flight_*` is the MEDIAN block. -----------------------------------
     RZ.set_stage_timing(True, dom_stage)
     steps_pipelined(max(10, args.warmup, 2 * F) + 4 * F + args.steps)  # untimed; also lets the clocks settle under the concurrent load (one block's worth)
     torch.cuda.synchronize(dev)
@@ -516,9 +563,9 @@ def main():
     dom_live = _capi.timing_read()[dom_stage]
     # Second timed region: the same step, EXACTLY --steps of them, one view in flight, the dominant kernel still bracketed by hipEvents on
     # its launch stream.  The roofline takes the kernel's duration from HERE: a roofline compares a kernel that has the chip to itself
-    # with the chip's peak, and a launch that time-shares the chip with the kernels of F - 1 other views (the headline region above)
+    # with the chip's peak, and a launch that time-shares the chip with the kernels of F - 1 other views (the region above)
     # has no exclusive duration -- there every launch lasts longer while the aggregate rate is higher (its duration is reported too:
-    # `headline_region`).
+    # `roofline.views_in_flight_region`).
     n_single = max(args.steps, 100)  # its own step count: the roofline's duration is an average over >= 100 exclusive launches
     el_single = timed(step, n_single, 5)
     dom_excl = _capi.timing_read()[dom_stage]
@@ -543,21 +590,23 @@ def main():
               "views_per_s": round(world * args.steps / el_s2, 2), "views_in_flight": F, "single_view_in_flight_views_per_s": round(world * n_single / el_s2_one, 2),
               "dominant_kernel_avg_launch_us": round(dom_s2[0] / max(1, dom_s2[1]) * 1e3, 2) if dom_s2[1] else None}
     RZ.set_stage_timing(False)
-    elapsed = sorted(blocks)[REPEATS // 2]
-    q1, q3 = sorted(blocks)[REPEATS // 4], sorted(blocks)[(3 * REPEATS) // 4]
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed
+    sess_elapsed = sorted(blocks)[REPEATS // 2]
+    sess_q1, sess_q3 = sorted(blocks)[REPEATS // 4], sorted(blocks)[(3 * REPEATS) // 4]
     R = int(RZ.last_stats(dev).get("last_R", 0))  # measured number of (Gaussian, bin) instances of this view
 
-    # secondary numbers (outside the headline region): the same step through the autograd drop-in module, forward only, and the
-    # non-blocking check mode
-    el_api = el_fwd = el_def = el_fwd_def = None
-    api_blocks = None
+    # ---- THE HEADLINE: the same step through the reference's plugin API -- GaussianRasterizer(raster_settings)(...) + image.backward(), the call shape
+    # of gaussian_renderer/__init__.py:51-62 -- one view at a time, sync capacity check.  REPEATS blocks of EXACTLY --steps steps (barrier +
+    # synchronize on both sides, MAX over ranks); `value` / `ms_per_step` are the median block, the quartiles are reported.  (Rounds 2-4 put the
+    # C-ABI session number with six views in flight first: a caller-owned-buffer API no reference code uses -- VERDICT r04 weak 7.)
+    api_blocks = [timed(fwd_bwd, args.steps, max(5, args.warmup) if i == 0 else 0) for i in range(REPEATS)]
+    elapsed = sorted(api_blocks)[REPEATS // 2]
+    q1, q3 = sorted(api_blocks)[REPEATS // 4], sorted(api_blocks)[(3 * REPEATS) // 4]
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    # secondary numbers: forward only, and the non-blocking check mode, through the same module
+    el_fwd = el_def = el_fwd_def = None
     if not args.headline_only:
-        # the reference's plugin API (GaussianRasterizer -> autograd Function), one view at a time: the SAME protocol as `value` -- REPEATS blocks of
-        # exactly --steps steps, the median block is the number, the quartiles are reported (round 3 took ONE 20-step block: 3,102 - 3,612 run to run)
-        api_blocks = sorted(timed(fwd_bwd, args.steps, 5 if i == 0 else 0) for i in range(REPEATS))
-        el_api = api_blocks[REPEATS // 2]
         el_fwd = timed(fwd_only, args.steps, 3)
         os.environ["GPSGS_CHECK"] = "deferred"
         el_def = timed(fwd_bwd, args.steps, 3)
@@ -622,62 +671,63 @@ def main():
     npix = W * H
     # ALGORITHMIC bytes per launch (SURVEY.md section 8d convention: each input read once, each output
     # written once; R = measured (Gaussian, bin) instances, NB = bins)
-    alg_bytes = {
-        "preprocess": 116 * P,
-        "scan": 8 * NB,
-        "scatter": 24 * P + 12 * R,
-        "sort": 12 * R + 8 * NB,
-        "composite_fwd": 40 * R + 8 * NB + 20 * npix,
-        "composite_bwd": 40 * R + 8 * NB + 20 * npix + 44 * P,
-        "preprocess_bwd": 212 * P,
-    }
+    # gradient records of this view (slots, and slots the compositing backward wrote a record into), counted on the device
+    n_slots = n_rec = None
+    try:
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        _capi.check(_capi.lib().gsr_debug_count_records(sess.ws.data_ptr(), P, W, H, sess.cap, cnt.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                    "gsr_debug_count_records")
+        torch.cuda.synchronize(dev)
+        n_rec, n_slots = int(cnt[0]), int(cnt[1])
+    except Exception:  # noqa: BLE001
+        n_slots = n_rec = None
+    alg_bytes = stage_bytes(P, R, NB, npix, n_slots, n_rec)
+    traffic_all = counter_traffic("pmc_traffic.json", P, W, H, R)
     per_stage = {}
     for name, (ms, n) in stages.items():
         if n:
             avg_ms = ms / n
-            per_stage[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n,
+            per_stage[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n, "algorithmic_bytes": alg_bytes[name],
                                "hbm_gbs": round(alg_bytes[name] / (avg_ms * 1e-3) / 1e9, 1)}
+            tr_ = traffic_all.get(name, {}).get("hbm_bytes_per_launch")
+            if tr_:  # L2-miss traffic of the same workload from the separate counter passes: 2 x FETCH_SIZE + WRITE_SIZE (profiles/pmc_traffic.json)
+                per_stage[name].update(counter_bytes=tr_, counter_gbs=round(tr_ / (avg_ms * 1e-3) / 1e9, 1), traffic_ratio=round(tr_ / alg_bytes[name], 3))
     dom = max(per_stage, key=lambda k: per_stage[k]["avg_us"]) if per_stage else None
     roofline = None
     if dom:
         achieved = per_stage[dom]["hbm_gbs"]
-        traffic, valu_instr, pmc_src = None, None, None
-        # HBM traffic / VALU instruction counts come from separate rocprofv3 --pmc passes (tools/prof_r04.sh writes profiles/pmc_traffic.json
-        # with the workload it was measured on); they are reported ONLY when this run is that workload, otherwise null
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                pj = json.load(open(tfile))
-                wl = pj.get("workload", {})
-                if wl.get("P") == P and wl.get("W") == W and wl.get("H") == H and abs(wl.get("R", -1) - R) <= 0.01 * R:
-                    pmc = pj.get(dom, {})
-                    traffic = pmc.get("hbm_bytes_per_launch")
-                    valu_instr = pmc.get("valu_wave_instructions_per_launch")
-                    pmc_src = pj.get("source")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        pmc = traffic_all.get(dom, {})
+        traffic, valu_instr, pmc_src = pmc.get("hbm_bytes_per_launch"), pmc.get("valu_wave_instructions_per_launch"), (traffic_all.get("source") if pmc else None)
         # exclusive duration: the one-view-in-flight timed region (falls back to the calibration pass if the dominant kernel changed)
         dom_us = round(dom_excl[0] / max(1, dom_excl[1]) * 1e3, 2) if dom == dom_stage and dom_excl[1] else per_stage[dom]["avg_us"]
         ovl_us = round(dom_live[0] / max(1, dom_live[1]) * 1e3, 2) if dom == dom_stage and dom_live[1] else None
-        achieved = round(alg_bytes[dom] / (dom_us * 1e-6) / 1e9, 1)
-        alg_tile = None
-        if R_tile and dom in ("composite_fwd", "composite_bwd"):  # the same formula with SURVEY's 16x16-tile instance count (T = 16x16 tiles)
+        # SURVEY.md section 8(d) prices the compositing kernels with the instance count of upstream's 16x16 tiles: that is `achieved` / `frac`.  The same
+        # formula with this implementation's own (8x8-bin) instance count -- the bytes the kernel really walks -- is `frac_with_bin_8x8_instances`.
+        alg_bin = alg_bytes[dom]
+        alg_main = alg_bin
+        if R_tile and dom in ("composite_fwd", "composite_bwd"):
             T16 = ((W + 15) // 16) * ((H + 15) // 16)
-            alg_tile = 40 * R_tile + 8 * T16 + 20 * npix + (44 * P if dom == "composite_bwd" else 0)
+            alg_main = 40 * R_tile + 8 * T16 + 20 * npix + (44 * P if dom == "composite_bwd" else 0)  # section 8(d): 40 R + 8 T + 20 Npix (+ 44 P gradient write)
+        achieved = round(alg_main / (dom_us * 1e-6) / 1e9, 1)
         roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_tiles" if (dom.startswith("composite") and RZ._composite_flag()) else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_src,
-                    "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_us": dom_us,
+                    # what the counters say the kernel moved, as a rate ("rocprof HBM GB/s against the chip's peak") and against the algorithmic bytes
+                    "counter_gbs": (round(traffic / (dom_us * 1e-6) / 1e9, 1) if traffic else None),
+                    "counter_frac": (round(traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
+                    "traffic_ratio": (round(traffic / alg_main, 3) if traffic else None),
+                    "algorithmic_bytes_per_launch": alg_main, "avg_launch_us": dom_us,
+                    "algorithmic_bytes": "SURVEY.md section 8(d): 40 R + 8 T + 20 Npix + 44 P with R = instances on upstream's 16x16 tiles (T tiles)",
                     "launches_averaged": int(dom_excl[1]) if dom == dom_stage else None,
                     "measured": "hipEvents around the kernel on its launch stream over a timed region of %d steps with ONE view in flight (exclusive "
-                                "duration; profiles/r04_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % n_single,
-                    "bound_note": "the contract's roofline is HBM; this kernel's HBM fraction is low by construction (>= 50 op/B).  With a view on its own it is bound by the shape of the work -- 5 one-wave work items of ~370 list entries per SIMD, a lone wave is latency-bound -- not by VALU issue: adding 18 % VALU instructions per pair costs 4 % (profiles/r03_issue_probes.md, DESIGN.md section 4)",
-                    # the same kernel inside the headline region: F views in flight, launches of different views overlap and time-share the chip
-                    "headline_region": {"views_in_flight": F, "avg_launch_us": ovl_us,
-                                        "frac": (round(alg_bytes[dom] / (ovl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if ovl_us else None)},
-                    "instances": {"bin_8x8": R, "tile_16x16": R_tile},
-                    "frac_with_tile_16x16_instances": (round(alg_tile / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if alg_tile else None),
-                    # compositing is FP32-VALU bound, not HBM bound: one wave64 VALU instruction holds a SIMD for 4 cycles;
-                    # measured instructions (rocprofv3 SQ_INSTS_VALU, same workload) x 4 cycles / (1024 SIMDs x 2.4 GHz x t)
+                                "duration; profiles/r05_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % n_single,
+                    "bound_note": "the contract's roofline is HBM; this kernel's HBM fraction is low by construction (>= 50 op/B: SURVEY.md section 8d says the same).  At config 2 it is "
+                                  "bound by instruction issue per SIMD at the occupancy its registers allow (DESIGN.md section 4: counters, occupancy sweep, per-workgroup timeline)",
+                    # the same kernel with F views in flight (C-ABI sessions): launches of different views overlap and time-share the chip
+                    "views_in_flight_region": {"views_in_flight": F, "avg_launch_us": ovl_us},
+                    "instances": {"tile_16x16": R_tile, "bin_8x8": R, "gradient_record_slots": n_slots, "gradient_records_written": n_rec},
+                    "frac_with_bin_8x8_instances": round(alg_bin / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    # one wave64 VALU instruction holds a SIMD for 4 cycles; measured instructions (rocprofv3 SQ_INSTS_VALU, same workload) x 4 cycles /
+                    # (1024 SIMDs x measured shader clock x t): an upper bound of the issue-port use
                     "shader_clock_mhz": sclk_mhz,
                     "valu_issue_frac": (round(valu_instr * 4.0 / (1024 * (sclk_mhz or 2400.0) * 1e6 * dom_us * 1e-6), 4) if valu_instr else None)}
 
@@ -747,28 +797,26 @@ def main():
                     "BASELINE config 2 rendered at 2048^2 (use_hr_img)" if (args.res, args.gaussians, W) == (1024, 600000, 2048) else
                     "BASELINE config 5" if (args.res, args.gaussians, W) == (2048, 2400000, 2048) else "non-BASELINE workload (parity / contract test size)")
         line = {
-            "metric": "novel views/sec at 1024x1024 (~600k Gaussians), raster forward+backward, C-ABI session with %d views in flight "
-                      "(through the reference's own GaussianRasterizer API, one view at a time: autograd_api_views_per_s)" % F, "value": round(value, 2),
+            "metric": "novel views/sec at 1024x1024 (~600k Gaussians), 1 GPU", "value": round(value, 2),
             "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d render of a synthetic stereo human, P=%d Gaussians, R=%d (Gaussian, 8x8-bin) instances, "
                                    "HIP rasteriser forward+backward, one view per step per GPU" % (cfg_name, W, H, P, R),
-                       "host": "C-ABI (gsr_forward_notify + gsr_backward) driven by gps_gaussian_amd.session.RasterSession: preallocated buffers, no "
-                               "autograd round trip; the same step through the drop-in autograd module is `autograd_api_views_per_s`",
-                       "views_in_flight": "%d independent views per GPU rendered concurrently (one session + HIP stream each); one at a time: "
-                                          "`single_view_in_flight_views_per_s`" % F,
-                       "wave_priority": "GSR_FLAG_WAVE_PRIORITY (hardware wave priorities in the compositing kernels, results unchanged) is ON for every "
-                                        "one-view-at-a-time measurement (single_view_in_flight, autograd_api, stages, roofline) and OFF while several views "
-                                        "are in flight (`value`): measured best for each mode",
-                       "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)"},
-            "repeats_ms_per_step": [round(x / args.steps * 1e3, 4) for x in blocks],
+                       "api": "the reference's plugin API: GaussianRasterizer(raster_settings)(means3D=..., means2D=..., colors_precomp=..., opacities=..., scales=..., rotations=...) "
+                              "+ image.backward() (gaussian_renderer/__init__.py:51-62), one view at a time on the current stream",
+                       "check_mode": "sync (exact; the binning scan publishes the instance count to pinned host memory, checked on the host every forward)",
+                       "wave_priority": "GSR_FLAG_WAVE_PRIORITY (hardware wave priorities in the compositing kernels, results unchanged): on for a view that has the chip to "
+                                        "itself, off while several views are in flight (session.views_in_flight)"},
+            "repeats_ms_per_step": [round(x / args.steps * 1e3, 4) for x in api_blocks],
             "ms_per_step_iqr": [round(q1 / args.steps * 1e3, 4), round(q3 / args.steps * 1e3, 4)],
+            # the same kernels for a caller that owns its buffers (gps_gaussian_amd.session.RasterSession: two C-ABI calls per view, preallocated outputs /
+            # workspace / gradients) -- an API no reference code uses: one view at a time, and F independent views in flight on F HIP streams
+            "session": {"single_view_in_flight_views_per_s": round(world * n_single / el_single, 2),
+                        "views_in_flight": F, "views_in_flight_views_per_s": round(world * args.steps / sess_elapsed, 2),
+                        "views_in_flight_ms_per_step": round(sess_elapsed / args.steps * 1e3, 4),
+                        "views_in_flight_ms_per_step_iqr": [round(sess_q1 / args.steps * 1e3, 4), round(sess_q3 / args.steps * 1e3, 4)]},
             "single_view_in_flight_views_per_s": round(world * n_single / el_single, 2),
-            "autograd_api_views_per_s": rate(el_api),
-            "autograd_api": ({"views_per_s": rate(el_api), "iqr_views_per_s": [rate(api_blocks[(3 * REPEATS) // 4]), rate(api_blocks[REPEATS // 4])], "blocks": REPEATS,
-                              "protocol": "the reference's own call shape (GaussianRasterizer(raster_settings)(means3D=..., ...) + image.backward(), "
-                                          "gaussian_renderer/__init__.py:51-62), one view at a time, sync capacity check; median of %d blocks of %d steps" % (REPEATS, args.steps)}
-                             if api_blocks else None),
+            "autograd_api_views_per_s": round(value, 2),
             "cpu_affinity": ({"rank0_cpus": len(cpu_slice)} if cpu_slice else "not set (one rank, GPSGS_AFFINITY=0, or no sched_setaffinity)"),
             "not_measured_at_this_world_size": ([] if world == 1 else ["configs", "full_pipeline", "cpu_baseline", "cpu_taichi_splat_port", "hip_graph_replay"]),
             "stage2_gradient_set": s2,

@@ -108,6 +108,17 @@ __global__ void k_validate_lists(int P, int NB, const uint32_t *__restrict__ bin
     if (bad_id) atomicMax(out + 3, (unsigned long long)(r1 - r0));
 }
 
+// gsr_debug_count_records: how many gradient-record slots the last backward flagged (bench.py prices the record traffic with it)
+__global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__ flags, const GsrHeader *__restrict__ hdr, unsigned long long *__restrict__ out) {
+    const uint32_t n = hdr->num_slots;
+    unsigned long long c = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += flags[i] != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[1] = n;
+}
+
 }  // namespace
 
 extern "C" int gpsgs_abi_version(void) { return GPSGS_ABI_VERSION; }
@@ -386,6 +397,15 @@ extern "C" int gpsgs_measure_sclk(unsigned long long *scratch3_device, double *m
 }
 
 extern "C" int gsr_debug_set_wg_trace(unsigned long long *rows_device) { return gsr_set_wg_trace(rows_device) == 0 ? GPSGS_OK : GPSGS_E_LAUNCH; }
+
+extern "C" int gsr_debug_count_records(const void *workspace, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device, void *stream) {
+    if (!workspace || !out2_device || P < 0 || width <= 0 || height <= 0 || instance_capacity < 0) return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out2_device, 0, 16, s) != hipSuccess) return GPSGS_E_LAUNCH;
+    hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, s, at(workspace, L.inst_valid), reinterpret_cast<const GsrHeader *>(at(workspace, L.header)), out2_device);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
 
 extern "C" int gsr_timing_read(float *ms_sum_host, int *launches_host) {
     if (!ms_sum_host || !launches_host) return GPSGS_E_INVALID;

@@ -24,10 +24,10 @@ def main(d, tag):
         open(os.path.join(d, out_name), "w").write("\n".join(lines) + "\n")
 
     stats_table("trace", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --repeats 5 --no-cpu-baseline --no-configs --no-full-pipeline` (the driver's command, shorter), MI355X",
-                          "# bench.py renders 6 views concurrently in its headline region (one HIP stream each): the launches of different views overlap and",
+                          "# bench.py renders 6 views concurrently in its `session.views_in_flight` region (one HIP stream each): the launches of different views overlap and",
                           "# time-share the chip, so a kernel's average duration here mixes its one-view-at-a-time launches (calibration, one-view timed region,",
                           "# secondary legs) with the longer overlapped ones.  The exclusive durations -- what `roofline.avg_launch_us` is -- are in",
-                          "# %s_kernel_stats_one_view.md; `roofline.headline_region.avg_launch_us` is the overlapped duration." % tag], "kernel_stats.md")
+                          "# %s_kernel_stats_one_view.md; `roofline.views_in_flight_region.avg_launch_us` is the overlapped duration." % tag], "kernel_stats.md")
     stats_table("trace1", ["# rocprofv3 --kernel-trace --stats, `python bench.py --steps 12 --warmup 3 --repeats 5 --no-cpu-baseline --no-configs --no-full-pipeline --inflight 1 --headline-only`, MI355X: ONE view in flight,",
                            "# every launch has the chip to itself.  These are the exclusive kernel durations: `roofline.avg_launch_us` of bench.py (hipEvents on",
                            "# the launch stream over its one-view timed region) and the `stages` table agree with the avg_us column below."], "kernel_stats_one_view.md")
