@@ -107,3 +107,18 @@ def test_world_1_through_rccl():
     d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["stage2_path"]["allreduce"].startswith("nccl, world 1 (forced"), d["stage2_path"]
     assert d["stage2_path"]["allreduce_alone_ms"] > 0 and d["not_measured_at_this_world_size"] == []   # the 20.6 MB RCCL all-reduce on its own
+
+
+def test_scale_shaped_dry_run_prints_one_record_per_n():
+    """tools/scale_dry_run.py: bench.py at N = 1 and 2 back to back with the driver's command shape, one parsed record per N (N = 2 on this 1-GPU box:
+    both ranks on device 0 over gloo -- a rehearsal of the multi-rank path, not a measurement)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_dry_run.py"), "--ns", "1,2", "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    recs = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    per_n = [x for x in recs if "n" in x]
+    assert [x["n"] for x in per_n] == [1, 2] and recs[-1]["scale_dry_run"] == "ok"
+    for x in per_n:
+        p = x["parsed"]
+        assert x["rc"] == 0 and p["n_gpus"] == x["n"] and p["steps"] == 3 and p["value"] > 0 and p["scaling"] == "weak" and x["consistency"]["fits_in_driver_run"]
+        assert p["stage2_path"]["n_gpus"] == x["n"]

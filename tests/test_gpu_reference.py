@@ -325,6 +325,39 @@ def test_launcher_world_1_with_the_real_networks(tmp_path):
         assert len(t[k]) == n and min(t[k]) > 0, (k, t[k])
 
 
+def test_launcher_with_stock_ddp_world_1_over_rccl_matches_the_grad_allreducer(tmp_path):
+    """--ddp: the reference's model inside torch's own DistributedDataParallel(find_unused_parameters=True), world size 1 over RCCL, the real networks
+    and GPSGS_ACCELERATE=all -- the first time DDP's reducer hooks meet the side streams of the batch render node (render_api._RenderBatch): the
+    raster backward runs on one stream per sample while DDP's buckets fire on the autograd thread's stream.  Same seeds, same data: the final
+    weights equal those of the GradAllReducer run to the reference's own run-to-run spread (eager atomics, MIOpen); validation runs inside both."""
+    import torch
+    import make_synthetic_dataset as M
+    data_root = str(tmp_path / "data")
+    M.make_dataset(data_root, res=256, n_train=2, n_val=2, quiet=True)
+    outs = {}
+    for tag, extra, port in (("reducer", [], "29561"), ("ddp", ["--ddp"], "29563"), ("reducer2", [], "29565")):
+        work = refenv.make_workdir(REF, str(tmp_path / ("w_" + tag)), {"stage1_ckpt": "None", "dataset": {"src_res": 256, "data_root": data_root}})
+        final = str(tmp_path / (tag + ".pt"))
+        res = _tool([os.path.join(ROOT, "tools", "launch_stage2.py"), "--reference", REF, "--workdir", work, "--steps", "5", "--exp-root", str(tmp_path / ("exp_" + tag)),
+                     "--save-final", final] + extra + ["batch_size", "2", "record.loss_freq", "2", "record.eval_freq", "3"],
+                    env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "GPSGS_DIST_FORCE": "1", "GPSGS_ACCELERATE": "all"})
+        assert res["world_size"] == 1 and res["steps"] == 5 and res["backend"] == "nccl" and res["ddp"] is (tag == "ddp"), res
+        shows = [f for dp, _, fs in os.walk(str(tmp_path / ("exp_" + tag))) for f in fs if dp.endswith("show")]
+        assert shows == ["3.jpg"], shows
+        outs[tag] = torch.load(final, map_location="cpu")
+
+    def rel(a, b):
+        num = sum(float(((a[k].double() - b[k].double()) ** 2).sum()) for k in a if a[k].is_floating_point())
+        den = sum(float((a[k].double() ** 2).sum()) for k in a if a[k].is_floating_point())
+        return (num / den) ** 0.5
+    assert set(outs["ddp"]) == set(outs["reducer"]) and not any(k.startswith("module.") for k in outs["ddp"])   # the reference's checkpoint keys
+    noise, d = rel(outs["reducer"], outs["reducer2"]), rel(outs["reducer"], outs["ddp"])
+    print({"ddp_vs_grad_allreducer_relative_weight_difference": d, "grad_allreducer_run_to_run": noise})
+    for v in outs["ddp"].values():
+        assert torch.isfinite(v).all()
+    assert d <= max(5.0 * noise, 2e-3), (d, noise)
+
+
 def test_train_stage2_reaches_the_fused_kernels_through_the_import_hook(tmp_path):
     """train_stage2.py as __main__, UNMODIFIED, twice with the same seeds: plain, and with GPSGS_ACCELERATE=all (gps-gaussian_amd/accelerate.py: the
     opt-in import hook rebinds pts2render / l1_loss / ssim / CorrBlockFast1D / upsample_flow / flow2depth / depth2pc to the fused kernels of SURVEY

@@ -8,7 +8,8 @@ The reference trains on ONE GPU (/root/reference/train_stage2.py:27-55 has no di
 pair with no data-path collective, so data parallelism is one process per GPU, each running the reference's own `Trainer` on its
 shard of the dataset, plus ONE exchange step per iteration: a mean all-reduce of the 5,144,408 network gradients (20.6 MB, one
 32 MiB bucket -- xGMI is point-to-point, ring collectives are per-link bound, so one large message) over RCCL (backend "nccl";
-"gloo" on CPU).  Nothing in the reference is edited; this file only
+"gloo" on CPU) -- by this package's GradAllReducer (default), or by torch's stock DistributedDataParallel (--ddp).  Nothing in the
+reference is edited; this file only
   * puts gps-gaussian_amd/dropin (the MI355X rasteriser / correlation sampler under the reference's import names) and then the
     reference on sys.path, plus stand-ins for yacs / cv2 / tensorboard when -- and only when -- the real packages are missing;
   * imports `train_stage2` WITHOUT executing its `__main__` block and repeats that block (train_stage2.py:183-207), with one repair the
@@ -120,6 +121,9 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="override cfg.num_steps")
     ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo")
     ap.add_argument("--exp-root", default=None, help="where experiments/<name>/ goes (default: the reference's cwd-relative 'experiments')")
+    ap.add_argument("--ddp", action="store_true", help="wrap the reference's model in torch's stock DistributedDataParallel(find_unused_parameters=True) instead of this "
+                                                       "package's GradAllReducer: DDP's reducer hooks then issue the gradient all-reduces (25 MiB buckets) during the backward")
+    ap.add_argument("--save-final", default=None, help="rank 0: torch.save the model's final state_dict here (tests compare the two exchange implementations)")
     ap.add_argument("--no-overlap", action="store_true", help="issue the gradient all-reduce after the whole backward (one 32 MiB bucket) instead of from "
                                                               "post-accumulate hooks while the backward of the earlier layers is still running (8 MiB buckets)")
     ap.add_argument("--pg-timeout-s", type=float, default=None, help="watchdog timeout of the collectives (default $GPSGS_PG_TIMEOUT_S, else 1800): must cover rank 0's "
@@ -217,14 +221,39 @@ def main(argv=None):
     np.random.seed(1314 + 1000 * rank)
 
     # ---- the one exchange step ------------------------------------------------------------------------------------------------------
-    reducer = D.GradAllReducer(trainer.model.parameters(), overlap=not args.no_overlap)
-    real_unscale = trainer.scaler.unscale_
+    reducer = None
+    if args.ddp:
+        # torch's own DistributedDataParallel around the reference's model (what the north star names).  find_unused_parameters: the reference
+        # constructs gru16 / gru32 but never runs them (core/update.py:105-106).  The Trainer keeps talking to `self.model` as before -- it calls
+        # self.model.raft_stereo.freeze_bn() (train_stage2.py:54,95) and saves self.model.state_dict() (:178) -- so the wrapper forwards unknown
+        # attributes to the wrapped module and keeps the reference's checkpoint keys (no "module." prefix).
+        if not dist.is_initialized():
+            raise SystemExit("launch_stage2 --ddp needs a process group (run under torch.distributed.run, or GPSGS_DIST_FORCE=1 at world size 1)")
+        from torch.nn.parallel import DistributedDataParallel
 
-    def unscale_after_allreduce(optimizer):
-        reducer()  # mean over ranks of the (scaled) gradients; unused parameters travel as zeros
-        return real_unscale(optimizer)
+        class _DDP(DistributedDataParallel):
+            def __getattr__(self, name):
+                try:
+                    return super().__getattr__(name)
+                except AttributeError:
+                    return getattr(super().__getattr__("module"), name)
 
-    trainer.scaler.unscale_ = unscale_after_allreduce
+            def state_dict(self, *a, **k):
+                return self.module.state_dict(*a, **k)
+
+            def load_state_dict(self, *a, **k):
+                return self.module.load_state_dict(*a, **k)
+
+        trainer.model = _DDP(trainer.model, device_ids=[local_rank] if use_cuda else None, find_unused_parameters=True, gradient_as_bucket_view=True)
+    else:
+        reducer = D.GradAllReducer(trainer.model.parameters(), overlap=not args.no_overlap)
+        real_unscale = trainer.scaler.unscale_
+
+        def unscale_after_allreduce(optimizer):
+            reducer()  # mean over ranks of the (scaled) gradients; unused parameters travel as zeros
+            return real_unscale(optimizer)
+
+        trainer.scaler.unscale_ = unscale_after_allreduce
     timing = _install_timing(TS, trainer, torch) if (args.timing and rank == 0 and use_cuda) else None
     # validation (train_stage2.py:92-96 -> run_eval) stays on rank 0, like logging and checkpoints -- but every rank passes through it: the others
     # wait at an EXPLICIT barrier until rank 0 is done, instead of running ahead into the next iteration's all-reduce and sitting in a collective
@@ -243,10 +272,15 @@ def main(argv=None):
     if timing is not None:
         with open(args.timing, "w") as f:
             json.dump(timing(), f)
+    if rank == 0 and args.save_final:
+        torch.save({k: v.detach().cpu() for k, v in trainer.model.state_dict().items()}, args.save_final)
     if rank == 0:
-        print(json.dumps({"launcher": "launch_stage2", "world_size": world, "steps": int(trainer.total_steps), "exchange": "mean all-reduce of %d gradients in %d bucket(s)"
-                          % (sum(p.numel() for p in reducer.params), len(reducer.buckets)), "backend": dist.get_backend() if dist.is_initialized() else None,
-                          "exchange_overlapped_with_backward": bool(reducer.overlap), "cpu_affinity": (len(cpus) if cpus else None)}))
+        n_par = sum(p.numel() for p in trainer.model.parameters() if p.requires_grad)
+        print(json.dumps({"launcher": "launch_stage2", "world_size": world, "steps": int(trainer.total_steps),
+                          "exchange": ("torch DistributedDataParallel(find_unused_parameters=True) over %d gradients" % n_par) if args.ddp else
+                                      "mean all-reduce of %d gradients in %d bucket(s)" % (sum(p.numel() for p in reducer.params), len(reducer.buckets)),
+                          "ddp": bool(args.ddp), "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "exchange_overlapped_with_backward": True if args.ddp else bool(reducer.overlap), "cpu_affinity": (len(cpus) if cpus else None)}))
     D.shutdown()
 
 

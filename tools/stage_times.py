@@ -16,13 +16,14 @@ ap.add_argument("--gaussians", type=int, default=600000)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--no-color-grad", action="store_true", help="the gradient set stage 2 differentiates (the colours are input pixels): k_composite_bwd_tiles<false>")
+ap.add_argument("--seed-offset", type=int, default=0, help="added to the synthetic scene's seed (bench.py's `configs` legs use 77)")
 ap.add_argument("--attributes", default="trained", help="'untrained': scales at the 0.01 m clamp, opacity ~0.5 (what random network weights give: configs 3 / 4)")
 a = ap.parse_args()
 if a.lib:
     _capi.LIB_PATH = os.path.abspath(a.lib)
 dev = torch.device("cuda:0")
 rr = a.render_res or a.res
-smp = S.make_stereo_sample(a.res, a.gaussians, seed=S.SEED, render_res=rr, attributes=a.attributes)
+smp = S.make_stereo_sample(a.res, a.gaussians, seed=S.SEED + a.seed_offset, render_res=rr, attributes=a.attributes)
 g = S.compact_sample(smp); cam = smp["novel_view"]
 names = ("means3D", "colors", "opacities", "scales", "rotations")
 t = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(not (a.no_color_grad and k == "colors")) for k in names}
@@ -56,7 +57,7 @@ for fam in a.families.split(","):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     img = step().detach(); torch.cuda.synchronize()
     gr = {k: t[k].grad.clone() for k in names if t[k].grad is not None} if not a.fwd_only else {}
-    out = {"family": fam, "ms_per_step": round(dt * 1e3, 4), "views_per_s": round(1 / dt, 1), "R": RZ.last_stats(dev).get("last_R"),
+    out = {"family": fam, "P": int(t["means3D"].shape[0]), "W": rr, "H": rr, "ms_per_step": round(dt * 1e3, 4), "views_per_s": round(1 / dt, 1), "R": RZ.last_stats(dev).get("last_R"),
            "stages_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in st.items() if v[1]}, "sum_us": round(sum(v[0] / v[1] for v in st.values() if v[1]) * 1e3, 1)}
     if ref is None:
         ref = (img, gr)
