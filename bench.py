@@ -200,6 +200,7 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         # compositing backward, read back by k_preprocess_bwd) -- counted on the device after a backward (212 P under-counts a
         # regime with ~100 slots per Gaussian)
         run("train", 1, 1)
+        torch.cuda.synchronize(dev)  # (the sessions run on their own streams)
         cnt = torch.zeros(2, dtype=torch.int64, device=dev)
         sess0 = lanes[0]["train"]
         _capi.check(_capi.lib().gsr_debug_count_records(sess0.ws.data_ptr(), P, render_res, render_res, sess0.cap, cnt.data_ptr(),
@@ -674,6 +675,7 @@ def main():
     # gradient records of this view (slots, and slots the compositing backward wrote a record into), counted on the device
     n_slots = n_rec = None
     try:
+        torch.cuda.synchronize(dev)
         cnt = torch.zeros(2, dtype=torch.int64, device=dev)
         _capi.check(_capi.lib().gsr_debug_count_records(sess.ws.data_ptr(), P, W, H, sess.cap, cnt.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                     "gsr_debug_count_records")
