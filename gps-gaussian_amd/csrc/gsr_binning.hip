@@ -254,10 +254,10 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
 }
 
 
-constexpr int SC_THREADS = 512;                          // threads of a scatter workgroup
-constexpr int SC_PER = GSR_BIN_THREADS / SC_THREADS;     // Gaussians per thread: a workgroup still owns the 1,024 Gaussians of one k_preprocess workgroup
+constexpr int SC_PER = 2;                                // Gaussians per thread: a workgroup owns the Gaussians of ONE k_preprocess workgroup (its recorded table)
+constexpr int SC_THREADS = GSR_BIN_THREADS / SC_PER;     // threads of a scatter workgroup
 
-// (three workgroups per CU: 768 slots, so that the 586 workgroups of a 600 k-Gaussian view are all resident)
+// (6 waves per SIMD: every workgroup of a 600 k-Gaussian view is resident at once)
 __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scatter(int P, const uint32_t *__restrict__ row_range, int bx, const GsrSplat *__restrict__ splats, const uint4 *__restrict__ binrec,
                                                        const uint32_t *__restrict__ wg_tab, const uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
                                                        uint64_t *__restrict__ keys, const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
@@ -275,7 +275,8 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         const int i = i0 + u * SC_THREADS + (int)threadIdx.x;
         rec[u] = i < P ? binrec[i] : make_uint4(0u, 0u, 0u, 0u);  // (P = the launch capacity: rows behind a row-range view's last Gaussian hold neutral records)
     }
-    constexpr int TPT = GSR_BLOCK_TAB / SC_THREADS;  // table entries per thread
+    constexpr int TPT_ALL = GSR_BLOCK_TAB / SC_THREADS;  // table entries per thread
+    constexpr int TPT = TPT_ALL < 4 ? TPT_ALL : 4;       // ... of which the first 4 x SC_THREADS (every box a coherent view produces) are requested up front
     uint32_t tent[TPT];
 #pragma unroll
     for (int k = 0; k < TPT; k++) tent[k] = tab[4 + k * SC_THREADS + (int)threadIdx.x];
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         }
     }
     if (inst_valid) {
-        // training: "no gradient record yet" for every slot of this workgroup's 1024 Gaussians (replaces a cap-byte memset).  Their slots are ONE
+        // training: "no gradient record yet" for every slot of this workgroup's Gaussians (replaces a cap-byte memset).  Their slots are ONE
         // contiguous run [gpart[blk], gpart[blk + 1]) -- cleared by the whole workgroup with 16-byte stores.
         for (uint32_t k = (s_beg & ~15u) + (uint32_t)threadIdx.x * 16u; k < s_nxt; k += SC_THREADS * 16u) {
             if (k >= s_beg && k + 16u <= s_nxt) {
@@ -350,6 +351,12 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
     for (int k = 0; k < TPT; k++) {
         const int t = k * SC_THREADS + (int)threadIdx.x;
         if (t < area) { s_cnt[t] = 0u; s_base[t] = toff[k] + tent[k] - 1u; }
+    }
+    for (int t = TPT * SC_THREADS + (int)threadIdx.x; t < area; t += SC_THREADS) {  // a box beyond the entries requested up front (uniform, rare)
+        const uint32_t e = tab[4 + t];
+        const int ty = t / tab_bw, tx = t - ty * tab_bw;
+        s_cnt[t] = 0u;
+        s_base[t] = (e ? bin_offset[(tab_by0 + ty) * bx + tab_bx0 + tx] : 0u) + e - 1u;
     }
     __syncthreads();
 #pragma unroll

@@ -18,14 +18,14 @@
 //   binrec[P]      16 bytes {depth bits, bin rect lo, hi, mask}: all k_scatter reads of a Gaussian.  mask bit k = the k-th cell (row-major) of its bin
 //                  rect passed the exact ellipse/bin test, computed once by k_preprocess (rects of more than 32 cells carry the bits of the test's
 //                  threshold instead and are re-tested by k_scatter from the splat record)
-//   wg_tab[P/1024][4+2048]  per binning workgroup: bin box + per-bin instance counts of its 1024 Gaussians, recorded by k_preprocess
+//   wg_tab[P/512][4+2048]   per binning workgroup: bin box + per-bin instance counts of its GSR_BIN_THREADS = 512 Gaussians, recorded by k_preprocess
 //                  and consumed by k_scatter (which then skips the box reduction, the table clearing and the counting loop)
 //   keys[cap]      u64 (depth_bits << 32 | gaussian id), binned, then sorted in LDS per bin
 //   point_list[cap] u32 sorted gaussian ids (what the compositing kernels walk)
 //   final_T[H*W], n_contrib[H*W]                         per-pixel state kept for the backward
 //   --- backward-only tail (a forward-only caller may pass a workspace without it) ---
-//   goff[P], gscan_part[P/1024+1]   exclusive prefix of every Gaussian's bin-rect area (its slots in inst_valid / inst_grad), kept as
-//                  (prefix inside its 1024-block, prefix of the blocks): both fall out of the forward for free
+//   goff[P], gscan_part[P/512+1]    exclusive prefix of every Gaussian's bin-rect area (its slots in inst_valid / inst_grad), kept as
+//                  (prefix inside its 512-block, prefix of the blocks): both fall out of the forward for free
 //   inst_valid[cap] one byte per (Gaussian, k-th cell of its bin rect) slot: cleared by k_scatter, set by the compositing backward
 //                  when it writes that instance's record
 //   inst_grad[cap] 32-byte records of per-INSTANCE partial sums {dcolor rgb, dmean2D xy, dconic xx xy yy}, GAUSSIAN-MAJOR (indexed by
@@ -48,7 +48,15 @@
 #define GSR_BINS_PER_WG 1 // compositing workgroup = ONE wave64 = one bin: the dispatcher then balances CUs at wave granularity
 #define GSR_CPAD 1       // u32 stride of the per-bin counters / cursors (32 = one 128-byte line each: measured no faster)
 #define GSR_SCAN_BLOCK 1024
-#define GSR_BIN_THREADS 1024 // Gaussians per binning workgroup (k_preprocess / k_scatter)
+#ifndef GSR_BIN_THREADS
+// Gaussians per binning workgroup (k_preprocess / k_scatter) = block of the per-Gaussian slot prefix (goff / gscan_part).  1,024 until round 5: a
+// 600 k-Gaussian view was 586 workgroups of 16 waves for 512 resident slots -- a second, nearly empty round of 74 workgroups on 74 CUs.  Measured
+// (tools/stage_times.py, config 2 / the untrained-heads regime): k_preprocess 33.8 -> 28.3 / 53 -> 43 us, k_scatter 15.5 -> 14.8 / 106 -> 101; 256: no
+// further gain for k_preprocess, k_scatter 18.8.
+#define GSR_BIN_THREADS 512
+#endif
+#define GSR_BIN_SHIFT (GSR_BIN_THREADS == 1024 ? 10 : GSR_BIN_THREADS == 512 ? 9 : 8)
+static_assert(GSR_BIN_THREADS == 1024 || GSR_BIN_THREADS == 512 || GSR_BIN_THREADS == 256, "binning workgroup size");
 #define GSR_BLOCK_TAB 2048   // bins in a binning workgroup's direct-indexed LDS table
 
 struct __attribute__((aligned(16))) GsrSplat {
@@ -111,7 +119,7 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     L.n_contrib = o;  o = gsr_align_up(o + npix * 4);
     L.total_fwd = o;
     L.goff = o;       o = gsr_align_up(o + (p + 1) * 4);
-    L.gscan_part = o; o = gsr_align_up(o + (p / GSR_SCAN_BLOCK + 2) * 4);
+    L.gscan_part = o; o = gsr_align_up(o + (p / GSR_BIN_THREADS + 2) * 4);
     L.inst_valid = o; o = gsr_align_up(o + c);
     L.inst_dop = o;   o = gsr_align_up(o + c * 4);
     L.inst_grad = o;  o = gsr_align_up(o + c * sizeof(GsrGradAcc));
@@ -268,13 +276,13 @@ __device__ __forceinline__ GsrMaskedHit gsr_masked_hit(const GsrHit &h, uint32_t
     return m;
 }
 
-// ---- the two binning passes of a workgroup of (up to) 1,024 consecutive Gaussians ----------------------------------------------------------
+// ---- the two binning passes of a workgroup of (up to) GSR_BIN_THREADS consecutive Gaussians ----------------------------------------------------------
 // COUNT pass (k_preprocess, gsr_block_bin<false>): histogram the workgroup's instances into the LDS table over its bin box, then ONE returning
 // global atomic per touched bin: bin_count[bin] += count.  The value it returns is this workgroup's BASE inside the bin's list; it is recorded
 // in `tab` = {bx0, by0, bw, bh, base + 1 per table entry (0: no instance)} for the scatter pass of the same Gaussians.
 // SCATTER pass (k_scatter, gsr_block_emit_*): slot = bin_offset[bin] + recorded base + rank inside the workgroup (LDS atomic) -- no global atomic,
 // no counting loop, no box reduction (round 5; until then the scatter pass reserved its slots with a second returning atomic per bin).
-// INCOHERENT input -- a bin box that does not fit the table (normal case: the ONE workgroup whose 1,024 Gaussians straddle the end of the first
+// INCOHERENT input -- a bin box that does not fit the table (normal case: the ONE workgroup whose Gaussians straddle the end of the first
 // source view and the start of the second: a box as tall as the subject) -- is counted band by band into a SECOND counter array
 // (reserve_fb -> bin_count_fb) and not recorded (tab[2] = -1); the scan places those instances BEHIND the recorded ones of their bin
 // (bin_cursor = offset + recorded count) and the scatter pass of that workgroup rebuilds its tables and reserves from that cursor

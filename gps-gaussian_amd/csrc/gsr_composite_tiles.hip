@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64, CG ? 2 : GSR_BWD_NOCOLOR_WAVES) void k_composit
             nC = c.x;
             const uint32_t lo = __float_as_uint(c.z), hi = __float_as_uint(c.w);
             const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff;
-            nRec = gpart[id >> 10] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
+            nRec = gpart[id >> GSR_BIN_SHIFT] + goff[id] + (uint32_t)((bin_y - y0) * (x1 - x0) + (bin_x - x0));
         }
     };
     stage(max_last - 1 - lane);

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
             if (k < wid) woff += v;
             tot += v;
         }
-        if (i < q.P) q.goff[i] = woff + x - area;  // prefix inside this block of 1024 Gaussians
+        if (i < q.P) q.goff[i] = woff + x - area;  // prefix inside this block of GSR_BIN_THREADS Gaussians
         if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan turns these into the prefix of the blocks
     }
     // the exact ellipse/bin test of every cell of the rect is evaluated ONCE, here; the outcomes are kept as a bit mask
@@ -399,10 +399,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         float g2x = 0.f;
         // this Gaussian's slots [s0, s1): from the slot prefix alone (the splat record would cost a 48-byte-stride read for 8 bytes)
-        const int gb = i >> 10;
+        const int gb = i >> GSR_BIN_SHIFT;
         const uint32_t gbase = gpart[gb];
         const uint32_t s0 = gbase + goff[i];
-        const uint32_t s1 = ((i & 1023) != 1023 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * 1024 < q.P ? gpart[gb + 1] : hdr->num_slots);
+        const uint32_t s1 = ((i & (GSR_BIN_THREADS - 1)) != GSR_BIN_THREADS - 1 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * GSR_BIN_THREADS < q.P ? gpart[gb + 1] : hdr->num_slots);
         // Flags first for runs of more than `ffm` slots.  The unconditional form (4 slots per step, every load in flight) wins while the records of a
         // view fit the 256 MB Infinity Cache and most slots hold one (config 2: 2.3 M slots x 37 B, 82 % written: 35.2 us against 37.9); beyond that the
         // kernel is HBM-bound and every record it does not read counts (measured: config 2 rendered at 2048^2 -- what stage 2 renders -- 91.9 -> 74.4 us,

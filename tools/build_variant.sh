@@ -10,6 +10,7 @@ COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fhip-fp3
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off -fno-slp-vectorize $flags -c gsr_preprocess.hip -o $out/gsr_preprocess.o &
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off -mllvm -simplifycfg-sink-common=false $flags -c gsr_binning.hip -o $out/gsr_binning.o &
 /opt/rocm/bin/hipcc $COMMON -fno-slp-vectorize $flags -c gsr_composite_tiles.hip -o $out/gsr_composite_tiles.o &
+/opt/rocm/bin/hipcc $COMMON -fno-slp-vectorize $flags -c gsr_composite.hip -o $out/gsr_composite.o &
 /opt/rocm/bin/hipcc $COMMON $flags -c capi.hip -o $out/capi.o &
 wait
 objs=""
