@@ -435,6 +435,7 @@ struct GsrFwdParams {
     // the other half of the upstream interface (GsrViewExt): SH colours instead of `colors`, precomputed covariances instead of scales + rotations
     const float *shs, *campos, *cov3D_precomp;  // [rows, sh_coeffs, 3], [3], [rows, 6]; NULL = not used
     uint32_t sh_degree, sh_coeffs;
+    float fx, fy;  // focal lengths in pixels, W / (2 tanfovx): set by gsr_launch_preprocess (two IEEE divisions per THREAD of a VALU-bound kernel otherwise)
 };
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binrec, uint32_t *wg_tab, uint32_t *bin_count, uint32_t *bin_count_fb, GsrHeader *hdr,
@@ -484,6 +485,7 @@ struct GsrBwdParams {
     const float *shs, *campos, *cov3D_precomp;  // as in GsrFwdParams
     uint32_t sh_degree, sh_coeffs;
     float *dL_dsh, *dL_dcov3D;  // [rows, sh_coeffs, 3], [rows, 6]: written when the matching input is given
+    float fx, fy;               // as in GsrFwdParams: set by gsr_launch_preprocess_bwd
 };
 
 #if defined(__HIPCC__)

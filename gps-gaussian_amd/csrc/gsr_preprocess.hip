@@ -247,7 +247,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
         const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
         const float pw = 1.f / (phw + 0.0000001f);
         const float ppx = phx * pw, ppy = phy * pw;
-        const float fx = (float)q.W / (2.f * q.tanfovx), fy = (float)q.H / (2.f * q.tanfovy);
+        const float fx = q.fx, fy = q.fy;
 
         float R[3][3], c6[6];
         if (use_cov) {  // the covariance is an input (upper triangle xx, xy, xz, yy, yz, zz), used as given: scale_modifier does not apply
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         pv[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
         pv[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
         pv[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
-        const float fx = (float)q.W / (2.f * q.tanfovx), fy = (float)q.H / (2.f * q.tanfovy);
+        const float fx = q.fx, fy = q.fy;
         const Ewa e = ewa_setup(pv, cam.v, fx, fy, q.tanfovx, q.tanfovy);
         float a, b, c;
         cov2d(e, c6, a, b, c);
@@ -629,8 +629,11 @@ void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binre
                            hipStream_t s) {
     if (p.P <= 0) return;
     const dim3 grid((p.P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), block(GSR_BIN_THREADS);
-    if (p.shs || p.cov3D_precomp) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, p, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
-    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, p, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
+    GsrFwdParams q = p;
+    q.fx = (float)q.W / (2.f * q.tanfovx);  // (the same correctly-rounded fp32 division the kernel used to evaluate per thread)
+    q.fy = (float)q.H / (2.f * q.tanfovy);
+    if (p.shs || p.cov3D_precomp) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
+    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,
@@ -641,6 +644,8 @@ void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, co
     static long thr = -2;  // GPSGS_DEBUG_FLAGS_FIRST=<slots>: development knob for the threshold of the flags-first gather (unset: chosen per view)
     if (thr == -2) { const char *e = getenv("GPSGS_DEBUG_FLAGS_FIRST"); thr = e ? atol(e) : -1; }
     q.flags_first_min = thr < 0 ? 0xffffffffu : (uint32_t)thr;
+    q.fx = (float)q.W / (2.f * q.tanfovx);
+    q.fy = (float)q.H / (2.f * q.tanfovy);
     if (q.shs || q.cov3D_precomp)
         hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
     else
