@@ -18,7 +18,7 @@ Host-side design notes (MI355X-first, not a translation of upstream's C++ glue):
     transparently re-runs with a larger capacity, so results are always exact.  `GPSGS_CHECK=deferred` never blocks:
     the header lands in pinned memory and is examined on the next call into this module; an overflow then raises
     (capacity grows for later calls).  `GPSGS_CHECK=none` never looks at the header at all: the call sequence is then a pure
-    stream of kernel launches + one memset, which is what a HIP graph capture (torch.cuda.graph) needs; the caller owns the
+    stream of kernel launches only, which is what a HIP graph capture (torch.cuda.graph) needs; the caller owns the
     capacity question (run the step once eagerly in sync mode first: the learnt capacity is reused), an overflowing view is
     simply not rendered (the workspace header says so).
 """
