@@ -481,7 +481,6 @@ struct GsrBwdParams {
     const int *radii;
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dscales, *dL_drotations;
     const uint32_t *row_range;  // as in GsrFwdParams
-    uint32_t flags_first_min;   // runs of more gradient-record slots than this read their flags before their records (k_preprocess_bwd); ~0u: chosen per view
     const float *shs, *campos, *cov3D_precomp;  // as in GsrFwdParams
     uint32_t sh_degree, sh_coeffs;
     float *dL_dsh, *dL_dcov3D;  // [rows, sh_coeffs, 3], [rows, 6]: written when the matching input is given

@@ -403,62 +403,56 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
         const uint32_t gbase = gpart[gb];
         const uint32_t s0 = gbase + goff[i];
         const uint32_t s1 = ((i & (GSR_BIN_THREADS - 1)) != GSR_BIN_THREADS - 1 && i + 1 < q.P) ? gbase + goff[i + 1] : ((gb + 1) * GSR_BIN_THREADS < q.P ? gpart[gb + 1] : hdr->num_slots);
-        // Flags first for runs of more than `ffm` slots.  The unconditional form (4 slots per step, every load in flight) wins while the records of a
-        // view fit the 256 MB Infinity Cache and most slots hold one (config 2: 2.3 M slots x 37 B, 82 % written: 35.2 us against 37.9); beyond that the
-        // kernel is HBM-bound and every record it does not read counts (measured: config 2 rendered at 2048^2 -- what stage 2 renders -- 91.9 -> 74.4 us,
-        // config 5 313.6 -> 230.9 us with the threshold at 4 instead of 16).  The slot count is in the header: a wave-uniform choice.
-        const uint32_t ffm = q.flags_first_min != 0xffffffffu ? q.flags_first_min : (hdr->num_slots > 4000000u ? 4u : 16u);
-        if (s1 - s0 > ffm) {
-            // LARGE rects (scales at their clamp: ~100 slots per Gaussian, of which the compositing backward wrote a handful -- the splat is hidden
-            // in most of its bins): read 16 FLAGS per step, then fetch only the records that exist, in slot order (the same
-            // summation order as below: bit-identical sums).  The unconditional form below moved 37 bytes for every slot: 2 GB and 1.4 ms per view
-            // in BASELINE config 4 with random weights (profiles/r04_config4_kernel_stats.md), 95 % of it records nobody had written.
-            // (flags are the bytes 0 / 1; they are read as ALIGNED 16-byte words covering the run -- the section is 256-byte aligned and padded, and
-            //  whatever lies outside [s0, s1) is masked off -- instead of 16 single-byte loads per step: one memory instruction per 16 slots.
-            //  Tried and reverted: streaming a wave's consecutive flag runs through a 4 KiB LDS tile with coalesced loads -- 307 us either way at
-            //  R = 3e7: ~24 % of the slots hold a record there, and what the kernel waits for is the scattered 36-byte record reads, not the flags.)
-            for (uint32_t base = s0 & ~15u; base < s1; base += 16u) {
-                const uint4 f = *reinterpret_cast<const uint4 *>(inst_valid + base);
-                auto nib = [](uint32_t w) { w &= 0x01010101u; return (w | (w >> 7) | (w >> 14) | (w >> 21)) & 0xFu; };
-                uint32_t m = nib(f.x) | (nib(f.y) << 4) | (nib(f.z) << 8) | (nib(f.w) << 12);
-                const uint32_t lo = s0 > base ? s0 - base : 0u, hi = min(16u, s1 - base);
-                m &= (0xFFFFu >> (16u - hi)) & ~((1u << lo) - 1u);
-                while (m) {
-                    const int u = __builtin_ctz(m);
-                    m &= m - 1u;
-                    const uint32_t ri = base + (uint32_t)u;
-                    const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri);
-                    const float4 b0 = r[0], b1 = r[1];
-                    const float b2 = inst_dop[ri];
-                    g0.x += b0.x; g0.y += b0.y; g0.z += b0.z; g0.w += b0.w;
-                    g1.x += b1.x; g1.y += b1.y; g1.z += b1.z; g1.w += b1.w;
-                    g2x += b2;
+        // FLAGS FIRST, FOUR RECORDS PER STEP: the flags of 32 slots (two aligned 16-byte words -- the section is 256-byte aligned and padded, whatever
+        // lies outside [s0, s1) is masked off -- both requested up front, the next pair while the current one is worked on), then the records of up to
+        // four FLAGGED slots at a time, all twelve loads in flight, in slot order: a fixed summation order.  A slot nobody wrote costs its flag byte,
+        // not 37 bytes: at config 2 a third of the slots (the splat is hidden, or below 1/255, in that bin), in the untrained-heads regime three
+        // quarters.  Until round 5 short runs were read unconditionally (4 slots per step, what does not exist dropped by a select) and only long runs
+        // flags-first, ONE record per step: this form measured 37.1 -> 32.1 us at config 2, 69 -> 60 rendered at 2048^2, 217 -> 191 at config 5,
+        // 305 -> 278 in the regime (tools/stage_times.py).  (Tried and reverted in round 4: streaming the flags through an LDS tile.)
+        if (s1 > s0) {
+            auto nib = [](uint32_t w) { w &= 0x01010101u; return (w | (w >> 7) | (w >> 14) | (w >> 21)) & 0xFu; };
+            auto bits16 = [&](const uint4 &f) { return nib(f.x) | (nib(f.y) << 4) | (nib(f.z) << 8) | (nib(f.w) << 12); };
+            const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t base = s0 & ~15u;
+            uint4 fa = *reinterpret_cast<const uint4 *>(inst_valid + base);
+            uint4 fb = base + 16u < s1 ? *reinterpret_cast<const uint4 *>(inst_valid + base + 16u) : zero4;
+            for (; base < s1; base += 32u) {
+                uint32_t m = bits16(fa) | (bits16(fb) << 16);
+                const uint32_t lo = s0 > base ? s0 - base : 0u, hi = s1 - base;
+                m &= ~((1u << lo) - 1u);
+                if (hi < 32u) m &= (1u << hi) - 1u;
+                const uint32_t nb = base + 32u;
+                if (nb < s1) {
+                    fa = *reinterpret_cast<const uint4 *>(inst_valid + nb);
+                    fb = nb + 16u < s1 ? *reinterpret_cast<const uint4 *>(inst_valid + nb + 16u) : zero4;
                 }
-            }
-        } else
-        for (uint32_t sl = s0; sl < s1; sl += 4) {
-            // 4 slots per step, branch-free: every load is unconditional (index clamped to this Gaussian's last slot) so that all 4
-            // flag and 12 record loads are in flight together; what does not exist is dropped by a SELECT afterwards (never a
-            // multiply: a slot without a record may hold anything).  The predicated form made the compiler wait for each record
-            // before issuing the next load.
-            float4 a0[4], a1[4];
-            float a2[4];
-            uint8_t vb[4];
+                while (m) {
+                    uint32_t ri[4];
+                    bool ok[4];
+                    const uint32_t first = base + (uint32_t)__builtin_ctz(m);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t ri = min(sl + u, s1 - 1u);
-                const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri);
-                vb[u] = inst_valid[ri];
-                a0[u] = r[0];
-                a1[u] = r[1];
-                a2[u] = inst_dop[ri];
-            }
+                    for (int u = 0; u < 4; u++) {
+                        ok[u] = m != 0u;
+                        ri[u] = ok[u] ? base + (uint32_t)__builtin_ctz(m) : first;  // (a missing one re-reads the first: a cache hit, dropped by the select)
+                        m &= m - 1u;  // (0 stays 0)
+                    }
+                    float4 a0[4], a1[4];
+                    float a2[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {  // fixed order: slot 0, 1, 2, 3 (adding +0 for a missing slot changes nothing)
-                const bool ok = (sl + u < s1) && vb[u] != 0;
-                g0.x += ok ? a0[u].x : 0.f; g0.y += ok ? a0[u].y : 0.f; g0.z += ok ? a0[u].z : 0.f; g0.w += ok ? a0[u].w : 0.f;
-                g1.x += ok ? a1[u].x : 0.f; g1.y += ok ? a1[u].y : 0.f; g1.z += ok ? a1[u].z : 0.f; g1.w += ok ? a1[u].w : 0.f;
-                g2x += ok ? a2[u] : 0.f;
+                    for (int u = 0; u < 4; u++) {
+                        const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri[u]);
+                        a0[u] = r[0];
+                        a1[u] = r[1];
+                        a2[u] = inst_dop[ri[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        g0.x += ok[u] ? a0[u].x : 0.f; g0.y += ok[u] ? a0[u].y : 0.f; g0.z += ok[u] ? a0[u].z : 0.f; g0.w += ok[u] ? a0[u].w : 0.f;
+                        g1.x += ok[u] ? a1[u].x : 0.f; g1.y += ok[u] ? a1[u].y : 0.f; g1.z += ok[u] ? a1[u].z : 0.f; g1.w += ok[u] ? a1[u].w : 0.f;
+                        g2x += ok[u] ? a2[u] : 0.f;
+                    }
+                }
             }
         }
         const float4 g2 = make_float4(g2x, 0.f, 0.f, 0.f);
@@ -641,9 +635,6 @@ void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, co
                                hipStream_t s) {
     if (p.P <= 0) return;
     GsrBwdParams q = p;
-    static long thr = -2;  // GPSGS_DEBUG_FLAGS_FIRST=<slots>: development knob for the threshold of the flags-first gather (unset: chosen per view)
-    if (thr == -2) { const char *e = getenv("GPSGS_DEBUG_FLAGS_FIRST"); thr = e ? atol(e) : -1; }
-    q.flags_first_min = thr < 0 ? 0xffffffffu : (uint32_t)thr;
     q.fx = (float)q.W / (2.f * q.tanfovx);
     q.fy = (float)q.H / (2.f * q.tanfovy);
     if (q.shs || q.cov3D_precomp)
