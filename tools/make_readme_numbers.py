@@ -68,7 +68,7 @@ def main():
     for k, v in st.items():
         L.append("| %s | %.1f | %.1f | %s | %s | %s |" % (k, v["avg_us"], v["algorithmic_bytes"] / 1e6, ("%.1f" % (v["counter_bytes"] / 1e6)) if "counter_bytes" in v else "",
                                                        v.get("traffic_ratio", ""), ("%.2f" % (v["counter_gbs"] / 1e3)) if "counter_gbs" in v else ""))
-    L += ["", "Roofline of the dominant kernel (`%s`, %.1f µs exclusive over %s launches): SURVEY §8(d) bytes %.1f MB -> %.0f GB/s = **%.3f of the 8 TB/s HBM peak**; with the implementation's own 8x8-bin instance count %.3f; "
+    L += ["", "Roofline of the dominant kernel (`%s`, %.1f µs exclusive, median block of %s launches): SURVEY §8(d) bytes %.1f MB -> %.0f GB/s = **%.3f of the 8 TB/s HBM peak**; with the implementation's own 8x8-bin instance count %.3f; "
           "by the counters %s GB/s (traffic ratio %s); VALU issue fraction %s at a measured %.0f MHz." % (
               rf["kernel"], rf["avg_launch_us"], rf.get("launches_averaged"), rf["algorithmic_bytes_per_launch"] / 1e6, rf["achieved"], rf["frac"], rf["frac_with_bin_8x8_instances"],
               rf.get("counter_gbs"), rf.get("traffic_ratio"), rf.get("valu_issue_frac"), rf.get("shader_clock_mhz") or 0)]
