@@ -410,6 +410,13 @@ def main():
     # one process per GPU, each host-bound in bursts (F streams of launches): every rank on its own slice of the CPUs (its GPU's NUMA node when
     # sysfs names one); a no-op at world size 1 and with GPSGS_AFFINITY=0
     cpu_slice = D.set_cpu_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), local_rank)
+    # ONE rank: the GPU legs run pinned to eight CPUs of one L3 domain next to the GPU (dist.pin_near_gpu: what INTEGRATION.md tells a training
+    # script to do -- the plugin path is ~240 us of two-thread host work per 250 us GPU step, and a scheduler that migrates it across a 256-CPU box
+    # makes it ~40 % slower); the CPU-heavy legs (full pipeline children, the OpenMP baseline) run with the original mask again
+    pinned_one_rank = False
+    if cpu_slice is None and world == 1:
+        cpu_slice = D.pin_near_gpu(local_rank)
+        pinned_one_rank = cpu_slice is not None
     _capi.lib()  # fail loudly if the HIP library is missing
 
     # ---- synthetic workload: one stereo pair per rank (different pose per rank), resident in HBM ------------------
@@ -665,6 +672,7 @@ def main():
     # ---- the full pipeline: BASELINE configs 3 / 4 with the reference's OWN scripts and networks, MEASURED IN THIS RUN -------------------------
     # (rank 0, N = 1; the reference build under oracle/_ref is the CALLER of the product here, executed by tools/run_reference.py in child processes)
     full_pipeline = None
+    D.restore_affinity()  # (a no-op unless pin_near_gpu() pinned this rank: everything below is CPU-heavy or runs in child processes)
     if rank == 0 and world == 1 and not args.headline_only and not args.no_full_pipeline and (args.res, args.gaussians, W) == (1024, 600000, 1024):
         torch.cuda.empty_cache()  # (the default workload only, like `configs`: a small functional run of bench.py does not start full-size networks)
         full_pipeline = full_pipeline_leg(args.full_pipeline_budget)
@@ -829,7 +837,9 @@ def main():
                         "views_in_flight_ms_per_step_iqr": [round(sess_q1 / args.steps * 1e3, 4), round(sess_q3 / args.steps * 1e3, 4)]},
             "single_view_in_flight_views_per_s": round(world * n_single / el_single, 2),
             "autograd_api_views_per_s": round(value, 2),
-            "cpu_affinity": ({"rank0_cpus": len(cpu_slice)} if cpu_slice else "not set (one rank, GPSGS_AFFINITY=0, or no sched_setaffinity)"),
+            "cpu_affinity": ({"rank0_cpus": len(cpu_slice), "cpus": sorted(cpu_slice)[:16],
+                              "how": ("dist.pin_near_gpu: one L3 domain on the GPU's NUMA node, GPU legs only" if pinned_one_rank else "dist.set_cpu_affinity: this rank's slice")}
+                             if cpu_slice else "not set (GPSGS_AFFINITY=0, no sched_setaffinity, or no topology information)"),
             "not_measured_at_this_world_size": ([] if world == 1 else ["configs", "full_pipeline", "cpu_baseline", "cpu_taichi_splat_port", "hip_graph_replay"]),
             "stage2_gradient_set": s2,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,

@@ -8,6 +8,7 @@ unmodified Trainer, not a translation of anything.  Everything here also runs on
 (tests/test_multiproc_gloo.py, world_size 2).
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -101,6 +102,107 @@ def set_cpu_affinity(local_rank, local_world, device_index=None, peer_device_ind
         except Exception:  # noqa: BLE001
             pass
         return set(mine)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def _cpu_busy_sample(interval_s=0.03):
+    """Per-CPU busy jiffies over a short interval (/proc/stat), {cpu: busy} -- {} where /proc/stat is not readable."""
+    def snap():
+        out = {}
+        for line in open("/proc/stat"):
+            if line.startswith("cpu") and line[3].isdigit():
+                f = line.split()
+                v = [int(x) for x in f[1:9]]
+                out[int(f[0][3:])] = sum(v) - v[3] - v[4]  # everything but idle and iowait
+        return out
+    try:
+        a = snap()
+        time.sleep(interval_s)
+        b = snap()
+        return {c: b[c] - a.get(c, 0) for c in b}
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+_affinity_before_pin = None
+_threads_before_pin = None
+
+
+def pin_near_gpu(device_index=0, n_cpus=8):
+    """ONE process driving one GPU through the autograd API (the reference's train_stage2.py, bench.py's `value`): pin the calling thread -- and every
+    thread it starts afterwards: the autograd engine's worker, the loader's -- to n_cpus CPUs of ONE L3 domain on the GPU's NUMA node, the least busy
+    domain right now.  A step of the drop-in rasteriser is ~250 us of GPU work fed by ~240 us of Python / PyTorch host work spread over two threads
+    (tools/host_timeline.py); left to the scheduler on a 256-CPU box that host work migrates between cores and sockets and runs ~40 % slower (measured
+    on one box, same run: forward prologue 73 -> 42 us, notification -> backward launched 82 -> 50 us, backward launched -> next forward launched
+    153 -> 100 us; the step went from host-bound, 272 us, to GPU-bound, 252 us).  Pinning to the whole NUMA node does NOT do it (257 us): it is the
+    shared L3 and the absence of migrations that count.  GPSGS_AFFINITY=0 switches it off.  restore_affinity() undoes it (CPU-heavy legs: an OpenMP
+    baseline, DataLoader workers).  -> the CPU set chosen, or None (left alone)."""
+    global _affinity_before_pin, _threads_before_pin
+    if os.environ.get("GPSGS_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = set(os.sched_getaffinity(0))
+        node = gpu_numa_cpus(device_index) if torch.cuda.is_available() else None
+        pool = (allowed & node) if node and (allowed & node) else allowed
+        if len(pool) <= n_cpus:
+            return None
+        # L3 domains of the pool (sysfs); without sysfs: aligned runs of 2 * n_cpus CPU numbers
+        groups = {}
+        for c in sorted(pool):
+            try:
+                key = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c).read().strip()
+            except Exception:  # noqa: BLE001
+                key = "run%d" % (c // (2 * n_cpus))
+            groups.setdefault(key, []).append(c)
+        busy = _cpu_busy_sample()
+        best = min(groups.values(), key=lambda cs: (sum(busy.get(c, 0) for c in cs) / len(cs), cs[0]))
+        # one hardware thread per core first (the lowest-numbered sibling), the siblings only if the domain has fewer cores than asked for
+        first, rest = [], []
+        for c in best:
+            try:
+                sib = sorted(_parse_cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read()))
+            except Exception:  # noqa: BLE001
+                sib = [c]
+            (first if c == sib[0] or sib[0] not in best else rest).append(c)
+        first.sort(key=lambda c: (busy.get(c, 0), c))
+        mine = (first + rest)[:n_cpus]
+        if _affinity_before_pin is None:
+            _affinity_before_pin = allowed
+            _threads_before_pin = torch.get_num_threads()
+        os.sched_setaffinity(0, mine)
+        try:
+            torch.set_num_threads(max(1, len(mine)))
+        except Exception:  # noqa: BLE001
+            pass
+        return set(mine)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def restore_affinity():
+    """Undo pin_near_gpu(): the calling thread and every other thread of the process get the original CPU set back.  -> that set, or None."""
+    global _affinity_before_pin, _threads_before_pin
+    if _affinity_before_pin is None or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        os.sched_setaffinity(0, _affinity_before_pin)
+        # ... and for every thread of the process that was started while pinned (an OpenMP pool created by a CPU tensor operation keeps its eight
+        # CPUs otherwise: bench.py's 256-thread CPU baseline then ran at 0.4x)
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    os.sched_setaffinity(int(tid), _affinity_before_pin)
+                except Exception:  # noqa: BLE001  (a thread that has just exited)
+                    pass
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            torch.set_num_threads(max(1, _threads_before_pin or len(_affinity_before_pin)))
+        except Exception:  # noqa: BLE001
+            pass
+        out, _affinity_before_pin = _affinity_before_pin, None
+        return out
     except Exception:  # noqa: BLE001
         return None
 

@@ -176,6 +176,30 @@ def test_cpulist_parser_and_affinity_without_topology():
             os.environ["GPSGS_AFFINITY"] = env
 
 
+def test_pin_near_gpu_and_restore():
+    """ONE rank driving one GPU through the autograd API: the calling thread is pinned to a few CPUs of one L3 domain (dist.pin_near_gpu) and can
+    be given its original CPUs back (CPU-heavy legs).  Without a GPU / topology files the pool is whatever the process may run on."""
+    import gps_gaussian_amd  # noqa: F401
+    from gps_gaussian_amd import dist as D
+    before = set(os.sched_getaffinity(0))
+    env = os.environ.pop("GPSGS_AFFINITY", None)
+    try:
+        if len(before) >= 3:
+            got = D.pin_near_gpu(0, 2)
+            assert got is not None and len(got) == 2 and got <= before and set(os.sched_getaffinity(0)) == got
+            assert D.pin_near_gpu(0, 2) is None                     # again, from the narrowed set: nothing left to choose from
+            assert D.restore_affinity() == before and set(os.sched_getaffinity(0)) == before
+            assert D.restore_affinity() is None                     # nothing to undo any more
+        assert D.pin_near_gpu(0, len(before)) is None               # asks for everything there is: left alone
+        os.environ["GPSGS_AFFINITY"] = "0"
+        assert D.pin_near_gpu(0, 1) is None and set(os.sched_getaffinity(0)) == before
+    finally:
+        os.sched_setaffinity(0, before)
+        os.environ.pop("GPSGS_AFFINITY", None)
+        if env is not None:
+            os.environ["GPSGS_AFFINITY"] = env
+
+
 def test_full_pipeline_leg_respects_its_time_budget():
     """bench.py's `full_pipeline` leg (BASELINE configs 3 / 4 in child processes) must never run past its budget: with no time left every entry says it was
     skipped -- and why -- instead of starting a full-size network run; without a reference build it says so."""
