@@ -408,8 +408,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     D.init(backend=backend, device=dev)  # "nccl" is RCCL on ROCm; no-op at world size 1
     # one process per GPU, each host-bound in bursts (F streams of launches): every rank on its own slice of the CPUs (its GPU's NUMA node when
-    # sysfs names one); a no-op at world size 1 and with GPSGS_AFFINITY=0
-    cpu_slice = D.set_cpu_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), local_rank)
+    # sysfs names one), narrowed to eight CPUs of one L3 domain inside it; a no-op at world size 1 and with GPSGS_AFFINITY=0
+    cpu_slice = D.set_cpu_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), local_rank, n_cpus=8)
     # ONE rank: the GPU legs run pinned to eight CPUs of one L3 domain next to the GPU (dist.pin_near_gpu: what INTEGRATION.md tells a training
     # script to do -- the plugin path is ~240 us of two-thread host work per 250 us GPU step, and a scheduler that migrates it across a 256-CPU box
     # makes it ~40 % slower); the CPU-heavy legs (full pipeline children, the OpenMP baseline) run with the original mask again

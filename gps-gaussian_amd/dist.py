@@ -68,7 +68,7 @@ def gpu_numa_cpus(device_index):
         return None
 
 
-def set_cpu_affinity(local_rank, local_world, device_index=None, peer_device_indices=None):
+def set_cpu_affinity(local_rank, local_world, device_index=None, peer_device_indices=None, n_cpus=None):
     """One process per GPU, and every process is host-bound in bursts (six HIP streams of launches per rank in bench.py, the DataLoader workers of
     the trainer): pin each rank to its own slice of the CPUs -- those of its GPU's NUMA node when sysfs names one, else an even split of whatever
     this process may run on -- so that 8 ranks do not migrate across sockets or pile onto the same cores.  GPSGS_AFFINITY=0 switches it off.
@@ -76,8 +76,9 @@ def set_cpu_affinity(local_rank, local_world, device_index=None, peer_device_ind
     when the mapping differs.  local_world must be the number of ranks ON THIS NODE: if the launcher did not say (no LOCAL_WORLD_SIZE) and the
     caller fell back to the world size of a multi-node job, the slices would be 1 / world of the node -- so a local_world larger than the visible
     GPU count is refused (returns None, with a warning) instead of idling most cores.  After pinning, torch's intra-op pool is sized to the slice
-    (it was sized for the whole machine at import time; N threads squeezed onto cores / N CPUs thrash).
-    Returns the CPU set chosen (or None: left alone)."""
+    (it was sized for the whole machine at import time; N threads squeezed onto cores / N CPUs thrash).  n_cpus: narrow the rank's slice further, to that
+    many CPUs of ONE L3 domain inside it (a rank that only drives its GPU, like bench.py: see pin_near_gpu; a trainer keeps the whole slice for
+    its DataLoader workers).  Returns the CPU set chosen (or None: left alone)."""
     if os.environ.get("GPSGS_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity") or local_world <= 1:
         return None
     try:
@@ -96,6 +97,8 @@ def set_cpu_affinity(local_rank, local_world, device_index=None, peer_device_ind
             sharers, me = max(1, len(same)), (same.index(local_rank) if local_rank in same else 0)
         per = max(1, len(pool) // sharers)
         mine = pool[me * per:(me + 1) * per] or pool
+        if n_cpus and len(mine) > n_cpus:
+            mine = _quiet_l3_cpus(mine, n_cpus)
         os.sched_setaffinity(0, mine)
         try:
             torch.set_num_threads(max(1, len(mine)))
@@ -125,6 +128,30 @@ def _cpu_busy_sample(interval_s=0.03):
         return {}
 
 
+def _quiet_l3_cpus(pool, n_cpus):
+    """n_cpus CPUs of ONE L3 domain out of `pool`: the domain that is least busy right now, one hardware thread per core first."""
+    # L3 domains of the pool (sysfs); without sysfs: aligned runs of 2 * n_cpus CPU numbers
+    groups = {}
+    for c in sorted(pool):
+        try:
+            key = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c).read().strip()
+        except Exception:  # noqa: BLE001
+            key = "run%d" % (c // (2 * n_cpus))
+        groups.setdefault(key, []).append(c)
+    busy = _cpu_busy_sample()
+    best = min(groups.values(), key=lambda cs: (sum(busy.get(c, 0) for c in cs) / len(cs), cs[0]))
+    # one hardware thread per core first (the lowest-numbered sibling), the siblings only if the domain has fewer cores than asked for
+    first, rest = [], []
+    for c in best:
+        try:
+            sib = sorted(_parse_cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read()))
+        except Exception:  # noqa: BLE001
+            sib = [c]
+        (first if c == sib[0] or sib[0] not in best else rest).append(c)
+    first.sort(key=lambda c: (busy.get(c, 0), c))
+    return (first + rest)[:n_cpus]
+
+
 _affinity_before_pin = None
 _threads_before_pin = None
 
@@ -147,26 +174,7 @@ def pin_near_gpu(device_index=0, n_cpus=8):
         pool = (allowed & node) if node and (allowed & node) else allowed
         if len(pool) <= n_cpus:
             return None
-        # L3 domains of the pool (sysfs); without sysfs: aligned runs of 2 * n_cpus CPU numbers
-        groups = {}
-        for c in sorted(pool):
-            try:
-                key = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c).read().strip()
-            except Exception:  # noqa: BLE001
-                key = "run%d" % (c // (2 * n_cpus))
-            groups.setdefault(key, []).append(c)
-        busy = _cpu_busy_sample()
-        best = min(groups.values(), key=lambda cs: (sum(busy.get(c, 0) for c in cs) / len(cs), cs[0]))
-        # one hardware thread per core first (the lowest-numbered sibling), the siblings only if the domain has fewer cores than asked for
-        first, rest = [], []
-        for c in best:
-            try:
-                sib = sorted(_parse_cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read()))
-            except Exception:  # noqa: BLE001
-                sib = [c]
-            (first if c == sib[0] or sib[0] not in best else rest).append(c)
-        first.sort(key=lambda c: (busy.get(c, 0), c))
-        mine = (first + rest)[:n_cpus]
+        mine = _quiet_l3_cpus(pool, n_cpus)
         if _affinity_before_pin is None:
             _affinity_before_pin = allowed
             _threads_before_pin = torch.get_num_threads()
