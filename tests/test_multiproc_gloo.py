@@ -167,6 +167,13 @@ def test_cpulist_parser_and_affinity_without_topology():
         os.sched_setaffinity(0, before)
         if len(before) >= 2:
             assert got[0] and got[1] and not (got[0] & got[1]) and (got[0] | got[1]) <= set(before)
+        if len(before) >= 8:                                                        # n_cpus: a rank that only drives its GPU narrows its slice to one L3 domain
+            narrow = []
+            for r in (0, 1):
+                os.sched_setaffinity(0, before)
+                narrow.append(D.set_cpu_affinity(r, 2, n_cpus=2))
+            os.sched_setaffinity(0, before)
+            assert all(n and len(n) == 2 for n in narrow) and narrow[0] <= got[0] and narrow[1] <= got[1]
         os.environ["GPSGS_AFFINITY"] = "0"
         assert D.set_cpu_affinity(0, 2) is None                                    # switched off
     finally:
