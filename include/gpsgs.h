@@ -217,7 +217,7 @@ int gsr_read_header(const void *workspace, GsrHeader *host_out, void *stream);
 int gsr_selftest(float *out4_device, void *stream);
 
 /* Diagnostic: after a gsr_backward on a training workspace, out2_device[0] = gradient-record slots that hold a record (one per (Gaussian, bin) instance
- * that received gradient), out2_device[1] = slots of the view (header.num_slots).  Enqueues a memset + one kernel; does not synchronise. */
+ * that received gradient), out2_device[1] = slots of the view (header.num_slots).  Enqueues a 16-byte memset + one kernel; does not synchronise. */
 int gsr_debug_count_records(const void *workspace, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device, void *stream);
 
 /* Profiling helper (not thread safe, not for use under graph capture): synchronises, then adds up the hipEvent
