@@ -673,6 +673,11 @@ def main():
     # (rank 0, N = 1; the reference build under oracle/_ref is the CALLER of the product here, executed by tools/run_reference.py in child processes)
     full_pipeline = None
     D.restore_affinity()  # (a no-op unless pin_near_gpu() pinned this rank: everything below is CPU-heavy or runs in child processes)
+    # for the record: the headline's step once more with every thread of the process back on all CPUs (what an unpinned training script gets on THIS
+    # box at THIS moment: host-bound on some boxes, profiles/r05_host_timeline.md) -- five blocks, the median
+    el_unpinned = None
+    if pinned_one_rank and not args.headline_only:
+        el_unpinned = sorted(timed(fwd_bwd, args.steps, 5 if i == 0 else 0) for i in range(5))[2]
     if rank == 0 and world == 1 and not args.headline_only and not args.no_full_pipeline and (args.res, args.gaussians, W) == (1024, 600000, 1024):
         torch.cuda.empty_cache()  # (the default workload only, like `configs`: a small functional run of bench.py does not start full-size networks)
         full_pipeline = full_pipeline_leg(args.full_pipeline_budget)
@@ -845,6 +850,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
             "forward_only_views_per_s": rate(el_fwd),
             "deferred_check_views_per_s": {"fwd_bwd": rate(el_def), "fwd": rate(el_fwd_def)},
+            "plugin_api_unpinned_views_per_s": rate(el_unpinned),
             "stages": per_stage,
             "stage2_path": stage2,
             "configs": configs,

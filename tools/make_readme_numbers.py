@@ -32,6 +32,10 @@ def main():
              d["value"], d["ms_per_step"], d["ms_per_step_iqr"][0], d["ms_per_step_iqr"][1]),
          "| the same step through a C-ABI session (caller-owned buffers), one view at a time | %.0f views/s | %.4f |" % (sess["single_view_in_flight_views_per_s"], 1e3 / sess["single_view_in_flight_views_per_s"]),
          "| C-ABI sessions, %d independent views in flight on %d HIP streams | %.0f views/s | %.4f |" % (sess["views_in_flight"], sess["views_in_flight"], sess["views_in_flight_views_per_s"], sess["views_in_flight_ms_per_step"])]
+    if d.get("plugin_api_unpinned_views_per_s"):
+        aff = d.get("cpu_affinity")
+        L.insert(len(L) - 2, "| `value`'s process is pinned to %s CPUs of one L3 domain next to the GPU (`dist.pin_near_gpu`); the same step with every thread back on all CPUs, this box, this run | %.0f views/s | %.4f |" % (
+            aff.get("rank0_cpus") if isinstance(aff, dict) else "?", d["plugin_api_unpinned_views_per_s"], 1e3 / d["plugin_api_unpinned_views_per_s"]))
     if d.get("forward_only_views_per_s"):
         L.append("| forward only (plugin API, no_grad); `GPSGS_CHECK=deferred` forward + backward | %.0f; %.0f views/s | %.4f; %.4f |" % (
             d["forward_only_views_per_s"], d["deferred_check_views_per_s"]["fwd_bwd"], 1e3 / d["forward_only_views_per_s"], 1e3 / d["deferred_check_views_per_s"]["fwd_bwd"]))
