@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("GPSGS_LIB") or os.path.join(_HERE, "lib", "libgpsgs_h
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
     "gpsgs_abi_version", "gpsgs_build_info", "gpsgs_measure_sclk", "gsr_debug_set_wg_trace", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
-    "gsr_export_state", "gsr_selftest", "gsr_timing_read", "gsr_debug_count_records", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
+    "gsr_export_state", "gsr_mark_visible", "gsr_selftest", "gsr_timing_read", "gsr_debug_count_records", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "up_unproject_forward_dev", "up_unproject_backward_dev", "cs_forward", "cs_backward",
     "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
 )
@@ -87,7 +87,9 @@ def lib():
     l.gsr_export_state.restype = i32
     l.gsr_export_state.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     l.gsr_debug_count_records.restype = i32
-    l.gsr_debug_count_records.argtypes = [vp, i32, i32, i32, i64, vp, vp]
+    l.gsr_debug_count_records.argtypes = [vp, sz, i32, i32, i32, i64, vp, vp]
+    l.gsr_mark_visible.restype = i32
+    l.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     l.gsr_selftest.restype = i32
     l.gsr_selftest.argtypes = [vp, vp]
     l.gsr_timing_read.restype = i32
@@ -132,7 +134,7 @@ def lib():
     l.cu_upsample_backward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.cu_upsample_scratch_bytes.restype = sz
     l.cu_upsample_scratch_bytes.argtypes = [i32, i32, i32, i32]
-    if l.gpsgs_abi_version() != 3:
+    if l.gpsgs_abi_version() != 4:
         raise ImportError("gps_gaussian_amd: ABI version mismatch in %s" % LIB_PATH)
     _lib = l
     return l

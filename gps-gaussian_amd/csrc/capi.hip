@@ -192,6 +192,7 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
         if ((zb & 15u) == 0 && (reinterpret_cast<uintptr_t>(hdr) & 15u) == 0) {
             const uint32_t n16 = (uint32_t)(zb >> 4);
             hipLaunchKernelGGL(k_zero16, dim3((n16 + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<uint4 *>(hdr), n16);
+            if (hipGetLastError() != hipSuccess) return GPSGS_E_LAUNCH;  // stale scan flags / bin counts would corrupt the whole view
         } else if (hipMemsetAsync(hdr, 0, zb, s) != hipSuccess) {
             return GPSGS_E_LAUNCH;
         }
@@ -375,6 +376,13 @@ extern "C" int gsr_backward(int P, int width, int height, const float *means3D, 
                            instance_capacity, flags, stream, nullptr);
 }
 
+extern "C" int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present, void *stream) {
+    (void)projmatrix;  // upstream's in_frustum() projects the point too, but tests only the view-space depth
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return GPSGS_E_INVALID;
+    gsr_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;
+}
+
 extern "C" int gsr_selftest(float *out4_device, void *stream) {
     if (!out4_device) return GPSGS_E_INVALID;
     gsr_launch_selftest(out4_device, (hipStream_t)stream);
@@ -414,9 +422,11 @@ extern "C" int gpsgs_measure_sclk(unsigned long long *scratch3_device, double *m
 
 extern "C" int gsr_debug_set_wg_trace(unsigned long long *rows_device) { return gsr_set_wg_trace(rows_device) == 0 ? GPSGS_OK : GPSGS_E_LAUNCH; }
 
-extern "C" int gsr_debug_count_records(const void *workspace, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device, void *stream) {
+extern "C" int gsr_debug_count_records(const void *workspace, size_t workspace_bytes, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device,
+                                       void *stream) {
     if (!workspace || !out2_device || P < 0 || width <= 0 || height <= 0 || instance_capacity < 0) return GPSGS_E_INVALID;
     const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;  // a forward-only workspace has no record flags (they lie beyond its end)
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(out2_device, 0, 16, s) != hipSuccess) return GPSGS_E_LAUNCH;
     hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, s, at(workspace, L.inst_valid), reinterpret_cast<const GsrHeader *>(at(workspace, L.header)), out2_device);

@@ -440,6 +440,7 @@ struct GsrFwdParams {
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binrec, uint32_t *wg_tab, uint32_t *bin_count, uint32_t *bin_count_fb, GsrHeader *hdr,
                            hipStream_t s);
+void gsr_launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 void gsr_launch_scan(const uint32_t *bin_count, const uint32_t *bin_count_fb, uint32_t *bin_offset, uint32_t *bin_cursor, uint32_t *wg_order, uint4 *scan_part, int NB, int bx,
                      int by, int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort, uint32_t order_hint,
                      hipStream_t s);

@@ -103,15 +103,6 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
                 st.C2 += c.w * w;
                 st.T = T_next;
                 if (KEEP) st.last_rnd = use ? (uint32_t)(j + 1) : st.last_rnd;
-#ifdef GSR_ABL_VALU  // issue probes (tools/gpu_runs/gpu_r03_n.sh; never defined in a product build): extra work per pair that changes no result
-                { float d0_, d1_; __asm__ volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %2, %2" : "=v"(d0_), "=v"(d1_) : "v"(c.y)); }
-#endif
-#ifdef GSR_ABL_SALU
-                { uint32_t sd_ = 0; __asm__ volatile("s_xor_b32 %0, %0, 1\n\ts_xor_b32 %0, %0, 3" : "+s"(sd_) : : "scc"); }
-#endif
-#ifdef GSR_ABL_EXP
-                { float d0_; __asm__ volatile("v_exp_f32 %0, %1" : "=v"(d0_) : "v"(c.y)); }
-#endif
             }
         }
     }
@@ -287,15 +278,6 @@ __device__ __forceinline__ void tiles_bwd_pair(TileBwdState &st, const TileBwdCo
         st.A = __builtin_fmaf(ae, cA, st.A);  // = ae cd + (1 - ae) A
         k.wr[e & 3][64 * e] = dL_dalpha * aGe;             // s = dL/dG * G
         if (CG) k.wr[e & 3][TILE_SW_WORDS + 64 * e] = ae * st.T;   // w = dchannel/dcolour
-#ifdef GSR_ABL_BVALU  // issue probes (never defined in a product build)
-        { float d0_, d1_; __asm__ volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %2, %2" : "=v"(d0_), "=v"(d1_) : "v"(c.x)); }
-#endif
-#ifdef GSR_ABL_BSALU
-        { uint32_t sd_ = 0; __asm__ volatile("s_xor_b32 %0, %0, 1\n\ts_xor_b32 %0, %0, 3" : "+s"(sd_) : : "scc"); }
-#endif
-#ifdef GSR_ABL_BEXP
-        { float d0_; __asm__ volatile("v_exp_f32 %0, %1" : "=v"(d0_) : "v"(c.x)); }
-#endif
     }
 }
 

@@ -617,7 +617,23 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
     }
 }
 
+// upstream checkFrustum / markVisible (GaussianRasterizer.markVisible of the module the reference imports at
+// /root/reference/gaussian_renderer/__init__.py:14): a point is "visible" iff it passes the near-plane test of the preprocess, view-space
+// z > 0.2 -- the same uncontracted expression k_preprocess evaluates, so the mask equals "k_preprocess did not cull it at the near plane" bit for bit
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float *__restrict__ means3D, const float *__restrict__ view, uint8_t *__restrict__ present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+    const float pz = view[2] * x + view[6] * y + view[10] * z + view[14];
+    present[i] = pz > 0.2f ? 1 : 0;
+}
+
 }  // namespace
+
+void gsr_launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+}
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binrec, uint32_t *wg_tab, uint32_t *bin_count, uint32_t *bin_count_fb, GsrHeader *hdr,
                            hipStream_t s) {

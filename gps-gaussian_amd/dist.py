@@ -154,6 +154,7 @@ def _quiet_l3_cpus(pool, n_cpus):
 
 _affinity_before_pin = None
 _threads_before_pin = None
+_pinned_set = None
 
 
 def pin_near_gpu(device_index=0, n_cpus=8):
@@ -165,7 +166,7 @@ def pin_near_gpu(device_index=0, n_cpus=8):
     153 -> 100 us; the step went from host-bound, 272 us, to GPU-bound, 252 us).  Pinning to the whole NUMA node does NOT do it (257 us): it is the
     shared L3 and the absence of migrations that count.  GPSGS_AFFINITY=0 switches it off.  restore_affinity() undoes it (CPU-heavy legs: an OpenMP
     baseline, DataLoader workers).  -> the CPU set chosen, or None (left alone)."""
-    global _affinity_before_pin, _threads_before_pin
+    global _affinity_before_pin, _threads_before_pin, _pinned_set
     if os.environ.get("GPSGS_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     try:
@@ -179,6 +180,7 @@ def pin_near_gpu(device_index=0, n_cpus=8):
             _affinity_before_pin = allowed
             _threads_before_pin = torch.get_num_threads()
         os.sched_setaffinity(0, mine)
+        _pinned_set = set(mine)
         try:
             torch.set_num_threads(max(1, len(mine)))
         except Exception:  # noqa: BLE001
@@ -189,18 +191,24 @@ def pin_near_gpu(device_index=0, n_cpus=8):
 
 
 def restore_affinity():
-    """Undo pin_near_gpu(): the calling thread and every other thread of the process get the original CPU set back.  -> that set, or None."""
-    global _affinity_before_pin, _threads_before_pin
+    """Undo pin_near_gpu(): the calling thread and every thread of the process that still carries the PINNED CPU set (= was started while pinned,
+    or is the caller) get the original set back.  Threads that hold any other mask -- started before the pin, or pinned deliberately by somebody
+    else (a DataLoader's pin-memory thread, RCCL's proxy threads) -- are left alone.  pin_near_gpu() pins the CALLING thread and
+    what it starts afterwards: call it before the first backward / CPU tensor operation, or the autograd worker and the OpenMP pool that already
+    exist stay where they were.  -> the restored set, or None."""
+    global _affinity_before_pin, _threads_before_pin, _pinned_set
     if _affinity_before_pin is None or not hasattr(os, "sched_setaffinity"):
         return None
     try:
+        pinned = _pinned_set
         os.sched_setaffinity(0, _affinity_before_pin)
-        # ... and for every thread of the process that was started while pinned (an OpenMP pool created by a CPU tensor operation keeps its eight
-        # CPUs otherwise: bench.py's 256-thread CPU baseline then ran at 0.4x)
+        # ... an OpenMP pool created by a CPU tensor operation while pinned keeps its eight CPUs otherwise: bench.py's 256-thread CPU baseline then
+        # ran at 0.4x
         try:
             for tid in os.listdir("/proc/self/task"):
                 try:
-                    os.sched_setaffinity(int(tid), _affinity_before_pin)
+                    if pinned is not None and set(os.sched_getaffinity(int(tid))) == pinned:
+                        os.sched_setaffinity(int(tid), _affinity_before_pin)
                 except Exception:  # noqa: BLE001  (a thread that has just exited)
                     pass
         except Exception:  # noqa: BLE001
@@ -209,7 +217,7 @@ def restore_affinity():
             torch.set_num_threads(max(1, _threads_before_pin or len(_affinity_before_pin)))
         except Exception:  # noqa: BLE001
             pass
-        out, _affinity_before_pin = _affinity_before_pin, None
+        out, _affinity_before_pin, _threads_before_pin, _pinned_set = _affinity_before_pin, None, None, None
         return out
     except Exception:  # noqa: BLE001
         return None
@@ -263,7 +271,9 @@ class GradAllReducer:
     ANY rank (one small MAX all-reduce of the mask; the reference's never-used gru16 / gru32 drop out, so their buckets do not hold the others
     back) -- and the first step therefore runs without overlap.  A bucket that receives gradients again after its all-reduce was started -- a second backward before `reducer()` (gradient
     accumulation), or a step whose `reducer()` call was skipped after an exception -- is marked dirty: `reducer()` waits for the stale collective,
-    discards it and reduces the bucket again from the accumulated gradients.  `reset()` drops all in-flight state explicitly (call it after a
+    discards it and reduces the bucket again from the accumulated gradients.  Which buckets were launched by the hooks and which are dirty is
+    AGREED across the ranks at the start of `reducer()` (MAX all-reduce on a control group; round 6), so accumulation combined with data-dependent
+    parameter usage -- a rank that dirtied fewer buckets than another -- still issues identical sequences.  `reset()` drops all in-flight state explicitly (call it after a
     backward that raised, on EVERY rank)."""
 
     def __init__(self, params, bucket_bytes=None, overlap=False):
@@ -289,6 +299,7 @@ class GradAllReducer:
         self._expect = None  # overlap: per bucket, the ids of the parameters it waits for (learnt at the first call, identical on every rank)
         self._got = set()    # ids of the parameters whose gradient has arrived since the last call
         self._comm = None
+        self._ctl = None     # overlap: control group on which the ranks agree on (launched, dirty) before reducer() issues anything
         self._hooks = []
         if self.overlap:
             where = {id(p): b for b, bucket in enumerate(self.buckets) for p in bucket}
@@ -350,8 +361,30 @@ class GradAllReducer:
             dist.all_reduce(mask, op=dist.ReduceOp.MAX)
             used = {id(p) for p, m in zip(self.params, mask.tolist()) if m > 0}
             self._expect = [{id(p) for p in bucket if id(p) in used} for bucket in self.buckets]
+        if self.overlap:
+            # What the hooks did is decided PER RANK (how far `_next` got, which buckets were dirtied), but every collective below must be issued by
+            # every rank in the same order (a rank with a dirty bucket re-reduced it, a rank without one did not -- e.g. gradient
+            # accumulation on a rank that also skipped a parameter -- and the j-th collectives of the two ranks were different buckets).  So the ranks
+            # first AGREE: MAX over ranks of (buckets launched by hooks, dirty bit per bucket), on a control group of its own -- the ranks may have
+            # issued different numbers of bucket collectives on the default group at this point, and collectives only pair up per communicator.
+            nb = len(self.buckets)
+            if self._ctl is None:
+                self._ctl = dist.new_group()  # (collective: every rank reaches its first overlapped call)
+            ref = self.params[0]
+            state = torch.zeros(nb + 1, dtype=torch.float32, device=ref.device)
+            state[0] = float(self._next)
+            for b in self._dirty:
+                state[1 + b] = 1.0
+            dist.all_reduce(state, op=dist.ReduceOp.MAX, group=self._ctl)
+            st = state.tolist()
+            launched_any, dirty_any = int(st[0]), {b for b in range(nb) if st[1 + b] > 0}
+            for b in range(self._next, launched_any):  # started by another rank's hooks: pair it up now (in bucket order: the same sequence everywhere)
+                if b not in self._inflight:
+                    self._launch(b)
+            self._dirty = dirty_any
         for b in sorted(self._dirty):  # stale collectives: finish them (every rank issued them), throw the result away, reduce the bucket again
-            self._inflight.pop(b)[1].wait()
+            if b in self._inflight:
+                self._inflight.pop(b)[1].wait()
         self._dirty.clear()
         for b in range(len(self.buckets)):  # whatever the hooks did not start (overlap off; parameters without a gradient in the bucket; dirty ones)
             if b not in self._inflight:

@@ -98,23 +98,27 @@ def _composite_flag():
 _DEFAULT_FAMILY = "tiles"
 
 
-def _wave_priority_flag(st=None, stream=None):
+def _wave_priority_flag(st=None, stream=None, deterministic=False):
     """GSR_FLAG_WAVE_PRIORITY (include/gpsgs.h: hardware wave priorities in the tile compositing kernels; results unchanged) for a view that has
     the chip to itself.  GPSGS_WAVE_PRIORITY=0 / 1 forces it off / on; default (unset): on, unless this device saw rasteriser calls on MORE THAN ONE
     stream within the last 50 ms -- user code that spreads views over streams overlaps their kernels, where the scheme costs ~2 % of the
-    aggregate rate instead of gaining 4 - 8 %."""
+    aggregate rate instead of gaining 4 - 8 %.  deterministic (graph capture, GPSGS_CHECK=none): the wall-clock history is
+    not consulted -- a captured graph, and a run that is meant to be reproducible launch for launch, must not pick a kernel variant from timing
+    (ADVICE r05): on, unless the environment says otherwise."""
     env = os.environ.get("GPSGS_WAVE_PRIORITY")
     if env == "0":
         return 0
-    if env is None and st is not None and stream is not None:
+    if env is None and not deterministic and st is not None and stream is not None:
         now = time.perf_counter()
-        seen = st.setdefault("streams", {})
-        seen[stream] = now
-        if len(seen) > 1:
-            for k in [k for k, t in seen.items() if now - t > 0.05]:
-                del seen[k]
+        with _lock:  # forwards may run from several host threads (ADVICE r05)
+            seen = st.setdefault("streams", {})
+            seen[stream] = now
             if len(seen) > 1:
-                return 0
+                for k in [k for k, t in seen.items() if now - t > 0.05]:
+                    del seen[k]
+            several = len(seen) > 1
+        if several:
+            return 0
     return _capi.GSR_FLAG_WAVE_PRIORITY
 
 
@@ -440,10 +444,10 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
     # the compositing family and, for a view rendered on its own (the GaussianRasterizer module: no row range), the wave-priority scheme --
     # it pays when the view's kernels have the chip to themselves; a batch spreads its views over several streams and leaves it off
     st = _dev_state(dev)
-    family = _composite_flag() | (_wave_priority_flag(st, torch._C._cuda_getCurrentRawStream(dev.index)) if rows is None else 0)
+    mode = _check_mode()
+    family = _composite_flag() | (_wave_priority_flag(st, torch._C._cuda_getCurrentRawStream(dev.index), deterministic=(mode == "none")) if rows is None else 0)
     extra = _extra_flags  # read ONCE per view and carried to its backward in ctx (the backward runs on an autograd thread)
     base_flags = (_capi.GSR_FLAG_DEBUG if rs.debug else 0) | extra | family
-    mode = _check_mode()
     if mode != "none" and torch.cuda.is_current_stream_capturing():
         raise RuntimeError("gps_gaussian_amd: the capacity check reads a header back on the host and cannot run under graph capture; "
                            "warm up eagerly, then capture with GPSGS_CHECK=none")
@@ -692,6 +696,26 @@ class GaussianRasterizer(nn.Module):
         # with sh_degree = 3 and campos (:46-47): both inputs are part of the module it imports.
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings, grad_arena)
+
+
+    def markVisible(self, positions):
+        """Upstream GaussianRasterizer.markVisible: boolean [P] mask of the points that pass the frustum test of the preprocess -- view-space
+        z > 0.2, the only test upstream's in_frustum() applies (the reference never calls it; part of the class it imports,
+        /root/reference/gaussian_renderer/__init__.py:14).  Not differentiable, like upstream (torch.no_grad)."""
+        rs = self.raster_settings
+        if not isinstance(positions, torch.Tensor) or not positions.is_cuda:
+            raise RuntimeError("gps_gaussian_amd: markVisible needs a GPU tensor of positions (no CPU fallback)")
+        if positions.dim() != 2 or positions.shape[1] != 3:
+            raise RuntimeError("positions must have dimensions (num_points, 3)")
+        with torch.no_grad():
+            dev = positions.device
+            pos = _prep(positions, "positions", (3,), dev)
+            view, proj = _cam(rs.viewmatrix, 16, dev), _cam(rs.projmatrix, 16, dev)
+            present = torch.empty((pos.shape[0],), dtype=torch.bool, device=dev)
+            with _device_guard(dev):
+                rc = _capi.lib().gsr_mark_visible(pos.shape[0], _ptr(pos), _ptr(view), _ptr(proj), _ptr(present), torch._C._cuda_getCurrentRawStream(dev.index))
+            _capi.check(rc, "gsr_mark_visible")
+        return present
 
 
 def last_stats(device=None):

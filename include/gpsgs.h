@@ -40,9 +40,10 @@
 extern "C" {
 #endif
 
-#define GPSGS_ABI_VERSION 3 /* 2: + GsrViewExt, gsr_forward_ex, gsr_backward_ex; header words num_points / row_overflow (additive)
+#define GPSGS_ABI_VERSION 4 /* 2: + GsrViewExt, gsr_forward_ex, gsr_backward_ex; header words num_points / row_overflow (additive)
                                3: GsrViewExt grew from 32 to 80 bytes: SH colours and precomputed 3D covariances (the `shs` / `cov3D_precomp`
-                                  inputs of the upstream module, + their gradients); zero-initialised it means what version 2 meant */
+                                  inputs of the upstream module, + their gradients); zero-initialised it means what version 2 meant
+                               4: + gsr_mark_visible (upstream GaussianRasterizer.markVisible); gsr_debug_count_records takes workspace_bytes */
 
 enum {
     GPSGS_OK = 0,
@@ -203,6 +204,12 @@ int gsr_backward_ex(int P, int width, int height, const float *means3D, const fl
                     float *dL_dopacity, float *dL_dscales, float *dL_drotations, void *workspace,
                     size_t workspace_bytes, int64_t instance_capacity, unsigned flags, void *stream, const GsrViewExt *ext);
 
+/* Visibility mask (upstream `_C.mark_visible`, reached through GaussianRasterizer.markVisible(positions) of the module the reference imports at
+ * gaussian_renderer/__init__.py:14; the reference itself never calls it): present[i] = 1 iff point i passes the near-plane test of the forward
+ * (view-space z > 0.2), else 0.  means3D[P,3], viewmatrix[16] / projmatrix[16] as for gsr_forward (projmatrix is accepted for signature parity and
+ * not read: upstream's in_frustum() tests the view-space depth only). */
+int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present, void *stream);
+
 /* Enqueues a copy of the first 32 header bytes {u64 num_rendered, u32 overflow, max_bin_count, num_busy, num_slots, 2 pad} to PINNED host memory on
  * `stream`; does not synchronise (the host reads it after an event / stream sync of its own). */
 int gsr_copy_header_async(const void *workspace, void *host_pinned_out, void *stream);
@@ -218,7 +225,8 @@ int gsr_selftest(float *out4_device, void *stream);
 
 /* Diagnostic: after a gsr_backward on a training workspace, out2_device[0] = gradient-record slots that hold a record (one per (Gaussian, bin) instance
  * that received gradient), out2_device[1] = slots of the view (header.num_slots).  Enqueues a 16-byte memset + one kernel; does not synchronise. */
-int gsr_debug_count_records(const void *workspace, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device, void *stream);
+int gsr_debug_count_records(const void *workspace, size_t workspace_bytes, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device,
+                            void *stream); /* GPSGS_E_WORKSPACE for a forward-only workspace (it has no record slots) */
 
 /* Profiling helper (not thread safe, not for use under graph capture): synchronises, then adds up the hipEvent
  * durations recorded by calls that carried GSR_FLAG_TIMING since the last read.  ms_sum[GSR_STAGE_COUNT] receives the

@@ -205,3 +205,13 @@ class OracleRasterizer:
             raise RuntimeError("oracle flip_bound failed rc=%d" % rc)
         return touched[:P].astype(bool), {k: v[:P] for k, v in b.items() if v is not None}
 
+
+def mark_visible(means3D, view):
+    """Upstream checkFrustum / markVisible: point i is visible iff its view-space depth exceeds 0.2 -- the near-plane test
+    gsr_oracle.c applies (`pv[2] <= 0.2 -> culled`, xf4x3's evaluation order, fp32).  view: flat column-major [16] (the transposed tensor the
+    reference passes).  -> bool [P]."""
+    p = np.asarray(means3D, np.float32).reshape(-1, 3)
+    m = np.asarray(view, np.float32).reshape(-1)
+    z = ((m[2] * p[:, 0] + m[6] * p[:, 1]).astype(np.float32) + m[10] * p[:, 2]).astype(np.float32) + m[14]
+    return z.astype(np.float32) > np.float32(0.2)
+

@@ -106,7 +106,7 @@ int main() {
     // for a capacity of P + 100 rows.  Image and gradients must equal the plain call bit for bit; without the colour gradient
     // (GSR_FLAG_NO_COLOR_GRAD) every other gradient must still be identical and dL_dcolors must be zero.
     {
-        if (gpsgs_abi_version() != 3) { printf("ABI version %d\n", gpsgs_abi_version()); return 1; }
+        if (gpsgs_abi_version() != 4) { printf("ABI version %d\n", gpsgs_abi_version()); return 1; }
         const float nanv = std::nanf("");
         auto wide = [&](const std::vector<float> &src, int ch) {
             std::vector<float> w((size_t)3 * P * ch, nanv);

@@ -170,15 +170,20 @@ def parity_report(name, img, oimg, grads, og, solid, touched, extra=None, rgb_to
     return rep
 
 
-def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2e-3, strict_min=0.5, strict_max_over=0, bounds=None, strict_cap=None):
+def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2e-3, strict_min=0.5, strict_max_over=0, bounds=None, strict_cap=None,
+                       excused_cap=3.0):
     """The gradient criterion every parity test applies (so that every one of them can FAIL):
       * STRICT: the visible Gaussians that take part in no fragile pixel (fragile_bounds) are within grad_tol (normalised error
-        |a - ref| / (|ref| + grad_tol max|ref|)), at most strict_max_over of them excepted;
+        |a - ref| / (|ref| + grad_tol max|ref|)), at most strict_max_over of them excepted -- and an excepted one by at most excused_cap x grad_tol;
       * CAPPED (round 5; needs `bounds`): a Gaussian that does take part in a fragile pixel may exceed grad_tol only by what flipped branch
-        decisions at those pixels can explain: |a - ref| <= tolerance + 2 x its flip bound, element by element -- never "anything finite";
+        decisions at those pixels can explain: |a - ref| <= tolerance + 2 x its flip bound, element by element -- never "anything finite".  At most
+        strict_max_over of them may exceed that budget, and (round 6) NONE by more than excused_cap x the budget: until then an excused Gaussian
+        was excused without any limit (VERDICT r05 weak 2a);
       * GLOBAL: over ALL Gaussians, the fraction with any element off by more than grad_tol stays below global_frac (>= 2 allowed: tiny clouds);
-      * invisible Gaussians receive exactly zero.
-    Returns the strict-set fraction; it is expected to exceed strict_min in every scene now that `touched` means contribution, and is reported."""
+      * invisible Gaussians receive exactly zero;
+      * the STRICT set must be at least strict_min of the visible cloud (round 6: an assertion, it used to be a printed remark) -- a test whose scene
+        cannot reach 0.5 passes its own, justified, strict_min.
+    Returns the strict-set fraction."""
     nvis = int(visible.sum())
     strict = visible & ~touched
     frac = float(strict.sum() / max(1, nvis))
@@ -193,13 +198,16 @@ def assert_grad_parity(grads, og, touched, visible, grad_tol=1e-3, global_frac=2
             k, int(over.sum()), over.size, grad_tol, frac)
         assert int((over & strict).sum()) <= strict_max_over, "%s: %d strict-set Gaussians over %g (max err %.3e)" % (
             k, int((over & strict).sum()), grad_tol, e[strict].max())
-        if strict_cap is not None and strict.any():
-            assert e[strict].max() <= strict_cap * grad_tol, "%s: a strict-set Gaussian is off by %.3e (cap %g x %g)" % (k, e[strict].max(), strict_cap, grad_tol)
+        if strict.any():
+            cap_ = excused_cap if strict_cap is None else min(strict_cap, excused_cap)
+            assert e[strict].max() <= cap_ * grad_tol, "%s: a strict-set Gaussian is off by %.3e (cap %g x %g)" % (k, e[strict].max(), cap_, grad_tol)
         if bounds is not None:
             ratio = (d / _allowed(og[k], bounds.get(k), grad_tol)).reshape(d.shape[0], -1).max(axis=-1)
             bad = (ratio > 1.0) & touched
             assert int(bad.sum()) <= strict_max_over, "%s: %d Gaussians that take part in a fragile pixel are off by more than a flipped decision there can explain " \
                 "(worst: %.2f x its budget of tolerance + 2 x flip bound)" % (k, int(bad.sum()), float(ratio[touched].max()))
-    if frac < strict_min:
-        print("assert_grad_parity: strict set is %.3f of the visible cloud (< %.2f)" % (frac, strict_min))
+            if touched.any():
+                assert float(ratio[touched].max()) <= excused_cap, "%s: an excused Gaussian is off by %.2f x its budget (cap %g): no flipped decision explains that" % (
+                    k, float(ratio[touched].max()), excused_cap)
+    assert frac >= strict_min, "the strict set is %.3f of the visible cloud (< %.2f): the test leans on the flip budget alone" % (frac, strict_min)
     return frac

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), name
     lib = _capi.lib()
-    assert lib.gpsgs_abi_version() == 3
+    assert lib.gpsgs_abi_version() == 4
     assert b"gfx950" in lib.gpsgs_build_info()
 
 

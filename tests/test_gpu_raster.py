@@ -542,8 +542,14 @@ def test_very_wide_image_takes_the_two_launch_scan():
     solid, touched, bounds = fragile_bounds(o, dpix)
     assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
     og = o.backward(dpix)
-    parity_report("wide_4096x2104", img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
-    assert_grad_parity(grads, og, touched, oradii > 0, bounds=bounds)
+    rep = parity_report("wide_4096x2104", img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
+    # strict_min override (conftest.assert_grad_parity asserts >= 0.5 by default): 2,306 visible splats of ~100-400 px radius over 8.6 M pixels -- each
+    # of the ~800 fragile pixels lies under dozens of them, so three quarters of this cloud take part in one (0.246 strict in round 5).  The scene
+    # exists for the two-launch scan, not for gradient coverage; what replaces the missing strict set is a TIGHTER cap on the excused ones: every
+    # touched Gaussian within HALF its flip budget (0.23 measured), not just within it.
+    assert_grad_parity(grads, og, touched, oradii > 0, bounds=bounds, strict_min=0.2)
+    worst = max(r.get("max_err_touched_over_budget", 0.0) for r in rep["grads"].values())
+    assert worst <= 0.5, worst
 
 
 def test_forward_backward_under_hip_graph_capture(monkeypatch):
@@ -1020,8 +1026,21 @@ def test_large_splats_gradients_through_lists_thousands_deep(family):
     assert (err[solid] > RGB_TOL).sum() <= 1e-5 * err.size
     # T carries ~1e-4 of accumulated rounding by the time it meets the 1e-4 stop threshold (see test_large_splats_tens_of_millions_of_instances): a
     # handful of pixels outside the fragility band stop one splat earlier or later than the oracle, each moving the few Gaussians under it
-    frac = assert_grad_parity(grads, og, touched, oradii > 0, strict_max_over=16, bounds=bounds)
-    parity_report("large_splats_gradients[%s]" % family, img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
+    frac = assert_grad_parity(grads, og, touched, oradii > 0, strict_max_over=16, bounds=bounds)  # (the excused ones: <= 3 x their budget, conftest)
+    # WHY a few Gaussians exceed the budget of the 1e-5 band (err / budget 1.305 for the tile family, 0.916 for the VALU one): the
+    # budget only knows the pixels within 1e-5 of a threshold.  Through lists a thousand entries deep T has accumulated ~1e-4 of relative rounding -- in a
+    # different order in the two families (the tile family forms the weight as T - T (1 - alpha)) -- so a stop at T (1 - alpha) < 1e-4 can fall the other
+    # way at a pixel that sits up to ~1e-4 from the threshold.  With the band the rounding really has (1e-4) the same errors must be INSIDE the budget,
+    # with no Gaussian excused: asserted here.
+    _, touched4, bounds4 = fragile_bounds(o, dpix, thresh=1e-4)
+    worst4 = 0.0
+    for k in grads:
+        d = np.abs(grads[k] - og[k])
+        ratio = (d / _allowed(og[k], bounds4.get(k), GRAD_TOL)).reshape(d.shape[0], -1).max(axis=-1)
+        worst4 = max(worst4, float(ratio[touched4].max()))
+    parity_report("large_splats_gradients[%s]" % family, img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds,
+                  extra=dict(worst_err_over_budget_with_1e4_band=worst4, touched_with_1e4_band=int(touched4.sum())))
+    assert worst4 <= 1.0, "a Gaussian is off by %.2f x the budget of the 1e-4 band" % worst4
 
 
 def test_row_interval_binning_never_drops_a_pair_the_per_cell_test_lists():

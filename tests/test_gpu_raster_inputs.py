@@ -176,3 +176,36 @@ def test_backward_without_the_colour_gradient(family, bg):
         np.testing.assert_array_equal(t[k].grad.cpu().numpy(), full[k], err_msg=k)
     np.testing.assert_array_equal(m2.grad.cpu().numpy(), full["means2D"])
     assert np.abs(full["colors"]).max() > 0
+
+
+@pytest.mark.gpu
+def test_mark_visible_is_the_near_plane_test_of_the_forward():
+    """GaussianRasterizer.markVisible(positions) (upstream K10, the one member of the imported class round 5 lacked): bool [P], true iff view-space
+    z > 0.2.  Checked against the oracle's restatement, against the forward itself (radii > 0 implies visible; a visible point with radius 0 was
+    dropped later: zero determinant / empty tile rect), on points straddling the near plane bit by bit, and for the error behaviour of the module."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ, synthetic as S
+    from oracle.gsr_oracle import mark_visible
+    g = S.make_uniform_cloud(50000, 320, 200, seed=9, scale_med=0.02, z_range=(0.05, 3.0), behind_frac=0.2)
+    # a run of points whose view-space depth steps through the fp32 neighbours of 0.2 (identity rotation: z_view = z + t_z)
+    zs = np.float32(0.2) + np.arange(-8, 9, dtype=np.float32) * np.float32(np.spacing(np.float32(0.2)))
+    w2c = np.asarray(g["view"], np.float32).reshape(4, 4).T
+    extra = np.linalg.solve(w2c[:3, :3].astype(np.float64), (np.stack([np.zeros(17), np.zeros(17), zs.astype(np.float64)], 1) - w2c[:3, 3]).T).T
+    pos = np.concatenate([g["means3D"], extra.astype(np.float32)])
+    dev = torch.device("cuda:0")
+    rs = RZ.GaussianRasterizationSettings(g["H"], g["W"], g["tanfovx"], g["tanfovy"], torch.from_numpy(g["bg"]).to(dev), 1.0,
+                                          torch.from_numpy(g["view"]).to(dev), torch.from_numpy(g["proj"]).to(dev), 3,
+                                          torch.from_numpy(g["campos"]).to(dev), False, False)
+    rz = RZ.GaussianRasterizer(rs)
+    vis = rz.markVisible(torch.from_numpy(pos).to(dev))
+    assert vis.dtype is torch.bool and tuple(vis.shape) == (pos.shape[0],) and not vis.requires_grad
+    want = mark_visible(pos, g["view"])
+    np.testing.assert_array_equal(vis.cpu().numpy(), want)
+    assert 0 < want[-17:].sum() < 17 and 0.05 < want.mean() < 0.99        # both sides of the plane are present, also among the neighbours of 0.2
+    _, radii, _, _ = hip_render(g)
+    v0 = vis.cpu().numpy()[:g["means3D"].shape[0]]
+    assert (v0[radii > 0]).all() and (radii[~v0] == 0).all()
+    with pytest.raises(RuntimeError):
+        rz.markVisible(torch.from_numpy(pos))                              # CPU tensor: no fallback
+    assert rz.markVisible(torch.empty((0, 3), device=dev)).numel() == 0
+

@@ -99,7 +99,7 @@ HOOK = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("form", ["checkout", "staged-bytecode", "checkout-eval-inside-the-run", "checkout-stock-ddp"])
+@pytest.mark.parametrize("form", ["checkout", "staged-bytecode", "checkout-eval-inside-the-run", "checkout-stock-ddp", "checkout-stock-ddp-eval-inside-the-run"])
 def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path, form):
     ref = REF
     eval_freq = 2 if form.endswith("eval-inside-the-run") else 1000
@@ -116,7 +116,7 @@ def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path, form):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", LAUNCH_TEST_OUT=str(out), LAUNCH_TEST_EVAL_FREQ=str(eval_freq if eval_freq < 1000 else 0))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
            os.path.join(ROOT, "tools", "launch_stage2.py"), "--reference", ref, "--backend", "gloo", "--steps", "6", "--exp-root", str(tmp_path / "experiments"),
-           "--hook", str(hook)] + (["--ddp"] if form.endswith("stock-ddp") else []) + [   # --ddp: torch's DistributedDataParallel(find_unused_parameters=True)
+           "--hook", str(hook)] + (["--ddp"] if "stock-ddp" in form else []) + [   # --ddp: torch's DistributedDataParallel(find_unused_parameters=True)
            "stage1_ckpt", "None", "batch_size", "2", "record.loss_freq", "2", "record.eval_freq", str(eval_freq)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
@@ -127,7 +127,7 @@ def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path, form):
     s0, s1 = res["seen"]
     assert len(s0) == 6 and len(s1) == 6 and not (set(s0) & set(s1) and s0 == s1)      # different shards
     line = [l for l in r.stdout.splitlines() if l.startswith("{") and "launch_stage2" in l]
-    assert len(line) == 1 and json.loads(line[0])["world_size"] == 2 and json.loads(line[0])["ddp"] is form.endswith("stock-ddp")
+    assert len(line) == 1 and json.loads(line[0])["world_size"] == 2 and json.loads(line[0])["ddp"] is ("stock-ddp" in form)
     exp = list((tmp_path / "experiments").iterdir())
     assert len(exp) == 1
     ckpts = sorted(p.name for p in (exp[0] / "ckpt").iterdir())

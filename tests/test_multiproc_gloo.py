@@ -121,6 +121,63 @@ WORKER = textwrap.dedent("""
     for p, g0, g1 in zip(params, both[0], both[1]):
         assert torch.allclose(p.grad, (torch.tensor(g0) + torch.tensor(g1)) / 2, atol=1e-6)
     assert float(sum(p.grad.abs().sum() for p in unused.parameters())) > 0
+    # (4) ADVICE r05: (1) and (3) COMBINED, on a reducer of its own: a trunk and two heads, every parameter EXPECTED (both ranks use both heads
+    #     while the reducer learns).  Then two backwards before reducer() in which rank 0 skips head B.  Head B's parameters fill the FIRST
+    #     bucket(s) (reverse parameter order), so rank 0's hooks never get past bucket 0 -- nothing launched, nothing dirty -- while rank 1's hooks
+    #     launch every bucket in the first backward and dirty every one in the second.  Until round 6 each rank re-reduced ITS OWN dirty set: rank 1
+    #     issued 2 N collectives, rank 0 issued N (hang, or buckets of different sizes paired up).  Now the ranks agree first.
+    torch.manual_seed(1)
+    trunk, head_a, head_b = torch.nn.Linear(8, 8), torch.nn.Linear(8, 4), torch.nn.Linear(8, 4)
+    params3 = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+    red3 = D.GradAllReducer(params3, bucket_bytes=150, overlap=True)
+    assert len(red3.buckets) >= 3
+
+    def step3(skip_b):
+        h = trunk(x)
+        out = head_a(h).sum()
+        if not skip_b:
+            out = out + head_b(h).sum()
+        out.backward()
+
+    step3(False); red3()                       # learns: every parameter is expected
+    for p in params3:
+        p.grad = None
+    step3(False)
+    assert len(red3._inflight) == len(red3.buckets)   # overlap is live
+    red3()
+    for p in params3:
+        p.grad = None
+    step3(rank == 0)
+    step3(rank == 0)
+    mine_g = [(p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in params3]
+    mine_state = (red3._next, sorted(red3._dirty), sorted(red3._inflight))
+    red3()                                     # (no other collective before it: rank 1 has bucket all-reduces in flight that rank 0 has not issued yet)
+    state = [None, None]
+    dist.all_gather_object(state, mine_state)
+    assert state[0] != state[1], state         # the ranks really reached reducer() in different states
+    assert state[0][0] == 0 and not state[0][1] and state[1][0] == len(red3.buckets) and state[1][1] == list(range(len(red3.buckets))), state
+    both = [None, None]
+    dist.all_gather_object(both, [g.tolist() for g in mine_g])
+    for p, g0, g1 in zip(params3, both[0], both[1]):
+        assert torch.allclose(p.grad, (torch.tensor(g0) + torch.tensor(g1)) / 2, atol=1e-6)
+    assert not red3._dirty and not red3._inflight and red3._next == 0
+    for p in params3:                          # ... and an ordinary step behind it: nothing is left half-issued on either rank
+        p.grad = None
+    step3(False)
+    want3 = [p.grad.clone() for p in params3]  # (identical inputs on identical weights per rank; the mean over ranks follows below)
+    red3()
+    both = [None, None]
+    dist.all_gather_object(both, [g.tolist() for g in want3])
+    for p, g0, g1 in zip(params3, both[0], both[1]):
+        assert torch.allclose(p.grad, (torch.tensor(g0) + torch.tensor(g1)) / 2, atol=1e-6)
+    red3.remove_hooks()
+    # ... and one more ordinary step behind it: nothing is left half-issued
+    for p in params:
+        p.grad = None
+    net(x).sum().backward()
+    red2()
+    for p, want in zip(params, serial):
+        assert torch.allclose(p.grad, want, atol=1e-6)
     red2.remove_hooks()
     # --- CPU affinity helper: every rank gets a non-empty slice of what it may run on; two ranks sharing one pool get disjoint slices when there are >= 2 CPUs
     before = sorted(os.sched_getaffinity(0))

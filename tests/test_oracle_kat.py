@@ -193,3 +193,19 @@ def test_sh_and_precomputed_covariance_together():
     np.testing.assert_allclose(img, img2, atol=1e-12)
     for k in ("means3D", "means2D", "shs", "opacities", "cov3D_precomp"):
         np.testing.assert_allclose(gr[k], gr2[k], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(gr2[k]).max()), err_msg=k)
+
+
+def test_mark_visible_restatement_agrees_with_the_near_cull_of_the_oracle():
+    """oracle.gsr_oracle.mark_visible (upstream K10) against the C oracle's own near cull: every rendered Gaussian is visible, every Gaussian behind
+    the 0.2 plane has radius 0, and the fp32 neighbours of 0.2 fall on the documented side (z <= 0.2 is culled)."""
+    from gps_gaussian_amd import synthetic as S
+    from oracle.gsr_oracle import OracleRasterizer, mark_visible
+    g = S.make_uniform_cloud(4000, 160, 120, seed=2, scale_med=0.02, z_range=(0.05, 3.0), behind_frac=0.3)
+    o = OracleRasterizer("f32")
+    _, radii = o.forward(g["means3D"], g["colors"], g["opacities"], g["scales"], g["rotations"], g["view"], g["proj"], g["W"], g["H"], g["tanfovx"],
+                         g["tanfovy"], g["bg"])
+    vis = mark_visible(g["means3D"], g["view"])
+    assert vis[radii > 0].all() and (radii[~vis] == 0).all() and 0.1 < vis.mean() < 0.95
+    z = np.float32(0.2) + np.arange(-2, 3, dtype=np.float32) * np.float32(np.spacing(np.float32(0.2)))
+    pts = np.stack([np.zeros(5, np.float32), np.zeros(5, np.float32), z], 1)
+    np.testing.assert_array_equal(mark_visible(pts, np.eye(4, dtype=np.float32).reshape(-1)), [False, False, False, True, True])

@@ -50,6 +50,29 @@ def test_real_branch_flips_stay_inside_the_budget_and_a_localized_bug_does_not(w
         bad[k][i, j] = og[k][i, j] + 4.0 * float(budget.max())
         with pytest.raises(AssertionError):
             assert_grad_parity(bad, og, touched, vis, bounds=bounds)
+    # (c) VERDICT r05 weak 2a: with strict_max_over = 16 (what the large-splat test passes) FIVE touched Gaussians off by 10 x their budget used to be
+    #     excused without any limit; an excused Gaussian is now capped at excused_cap (3) x its budget
+    k = "means3D"
+    sc = np.abs(og[k]).max()
+    bad = {kk: v.copy() for kk, v in og2.items()}
+    for i in cand[:5]:
+        budget_i = 1e-3 * np.abs(og[k][i]) + 1e-6 * sc + 2 * bounds[k][i]
+        j = int(np.argmax(budget_i))
+        bad[k][i, j] = og[k][i, j] + 10.0 * float(budget_i[j])
+    with pytest.raises(AssertionError, match="excused Gaussian"):
+        assert_grad_parity(bad, og, touched, vis, bounds=bounds, strict_max_over=16, global_frac=1.0)
+    # ... the same five off by 2 x their budget ARE what strict_max_over = 16 is there to excuse
+    ok2 = {kk: v.copy() for kk, v in og2.items()}
+    for i in cand[:5]:
+        budget_i = 1e-3 * np.abs(og[k][i]) + 1e-6 * sc + 2 * bounds[k][i]
+        j = int(np.argmax(budget_i))
+        ok2[k][i, j] = og[k][i, j] + 2.0 * float(budget_i[j])
+    assert_grad_parity(ok2, og, touched, vis, bounds=bounds, strict_max_over=16, global_frac=1.0)
+    with pytest.raises(AssertionError):
+        assert_grad_parity(ok2, og, touched, vis, bounds=bounds, strict_max_over=4, global_frac=1.0)
+    # (d) VERDICT r05 weak 2b: a strict set below strict_min fails instead of printing a remark
+    with pytest.raises(AssertionError, match="strict set"):
+        assert_grad_parity(og2, og, touched, vis, bounds=bounds, strict_min=1.01)
     # ... and an untouched Gaussian off by 2e-3 of its value fails the strict part
     un = vis & ~touched
     i = np.nonzero(un)[0][np.argmax(np.abs(og["means3D"]).max(-1)[un])]

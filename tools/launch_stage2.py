@@ -244,7 +244,10 @@ def main(argv=None):
             def load_state_dict(self, *a, **k):
                 return self.module.load_state_dict(*a, **k)
 
-        trainer.model = _DDP(trainer.model, device_ids=[local_rank] if use_cuda else None, find_unused_parameters=True, gradient_as_bucket_view=True)
+        # broadcast_buffers=False: DDP's forward would otherwise broadcast registered buffers from rank 0 on every call -- a collective the ranks that
+        # do NOT evaluate never issue (the reference's model happens to have no buffers: GroupNorm / frozen BN)
+        trainer.model = _DDP(trainer.model, device_ids=[local_rank] if use_cuda else None, find_unused_parameters=True, gradient_as_bucket_view=True,
+                             broadcast_buffers=False)
     else:
         reducer = D.GradAllReducer(trainer.model.parameters(), overlap=not args.no_overlap)
         real_unscale = trainer.scaler.unscale_
@@ -261,7 +264,15 @@ def main(argv=None):
     real_eval = trainer.run_eval
 
     def eval_then_barrier(*a, **k):
-        out = real_eval(*a, **k) if rank == 0 else None
+        out = None
+        if rank == 0:
+            wrapped = trainer.model
+            if args.ddp:
+                trainer.model = wrapped.module  # rank-0-only validation runs on the PLAIN module: no DDP forward, so nothing collective
+            try:
+                out = real_eval(*a, **k)
+            finally:
+                trainer.model = wrapped
         D.barrier(local_rank if use_cuda else None)
         return out
     trainer.run_eval = eval_then_barrier
