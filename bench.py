@@ -203,7 +203,7 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         torch.cuda.synchronize(dev)  # (the sessions run on their own streams)
         cnt = torch.zeros(2, dtype=torch.int64, device=dev)
         sess0 = lanes[0]["train"]
-        _capi.check(_capi.lib().gsr_debug_count_records(sess0.ws.data_ptr(), sess0.ws.numel(), P, render_res, render_res, sess0.cap, cnt.data_ptr(),
+        _capi.check(_capi.lib().gsr_debug_count_records(sess0.ws.data_ptr(), sess0.ws.numel(), P, render_res, render_res, sess0.cap, sess0.bin_cap, cnt.data_ptr(),
                                                         torch.cuda.current_stream(dev).cuda_stream), "gsr_debug_count_records")
         torch.cuda.synchronize(dev)
         n_rec, n_slots = int(cnt[0]), int(cnt[1])
@@ -636,7 +636,7 @@ def main():
     # projected centres the forward left in its workspace (not timed)
     R_tile = None
     try:
-        st_ = RZ.export_state(sess.ws, P, W, H, sess.cap)
+        st_ = RZ.export_state(sess.ws, P, W, H, sess.cap, sess.bin_cap)
         xy, rad = st_["xy"], sess.radii.float()
         gx, gy = (W + 15) // 16, (H + 15) // 16
         x0 = ((xy[:, 0] - rad) / 16).to(torch.int32).clamp(0, gx); x1 = ((xy[:, 0] + rad + 15) / 16).to(torch.int32).clamp(0, gx)
@@ -700,7 +700,7 @@ def main():
     try:
         torch.cuda.synchronize(dev)
         cnt = torch.zeros(2, dtype=torch.int64, device=dev)
-        _capi.check(_capi.lib().gsr_debug_count_records(sess.ws.data_ptr(), sess.ws.numel(), P, W, H, sess.cap, cnt.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+        _capi.check(_capi.lib().gsr_debug_count_records(sess.ws.data_ptr(), sess.ws.numel(), P, W, H, sess.cap, sess.bin_cap, cnt.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                     "gsr_debug_count_records")
         torch.cuda.synchronize(dev)
         n_rec, n_slots = int(cnt[0]), int(cnt[1])

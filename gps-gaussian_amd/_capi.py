@@ -7,7 +7,7 @@ LIB_PATH = os.environ.get("GPSGS_LIB") or os.path.join(_HERE, "lib", "libgpsgs_h
 
 # every symbol include/gpsgs.h declares (tests/test_capi_symbols.py cross-checks this list against the header)
 SYMBOLS = (
-    "gpsgs_abi_version", "gpsgs_build_info", "gpsgs_measure_sclk", "gsr_debug_set_wg_trace", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
+    "gpsgs_abi_version", "gpsgs_build_info", "gpsgs_measure_sclk", "gsr_debug_set_wg_trace", "gsr_workspace_bytes", "gsr_workspace_bytes_forward_only", "gsr_workspace_bytes_ex", "gsr_direct_lists_ok", "gsr_forward", "gsr_forward_notify", "gsr_forward_ex", "gsr_backward", "gsr_backward_ex", "gsr_copy_header_async", "gsr_read_header",
     "gsr_export_state", "gsr_mark_visible", "gsr_selftest", "gsr_timing_read", "gsr_debug_count_records", "gsr_pack_scratch_bytes", "gsr_pack_views", "gsr_pack_views_backward", "fl_scratch_bytes",
     "fl_l1_ssim_forward", "fl_l1_ssim_backward", "up_unproject_forward", "up_unproject_backward", "up_unproject_forward_dev", "up_unproject_backward_dev", "cs_forward", "cs_backward",
     "cv_build_forward", "cv_build_backward", "cs_lookup_forward", "cs_lookup_backward", "cu_upsample_forward", "cu_upsample_backward", "cu_upsample_scratch_bytes",
@@ -38,7 +38,7 @@ class GsrHeader(C.Structure):
 class GsrViewExt(C.Structure):
     """Optional extras of one view (include/gpsgs.h): device pointer to the {begin, end} row range, work-order hint, and (ABI 3) the SH-colour /
     precomputed-covariance inputs of the upstream interface with their gradient outputs."""
-    _fields_ = [("row_range", C.c_void_p), ("order_hint", C.c_uint32), ("sh_degree", C.c_uint32), ("sh_coeffs", C.c_uint32), ("reserved0", C.c_uint32),
+    _fields_ = [("row_range", C.c_void_p), ("order_hint", C.c_uint32), ("sh_degree", C.c_uint32), ("sh_coeffs", C.c_uint32), ("bin_capacity", C.c_uint32),
                 ("shs", C.c_void_p), ("campos", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("reserved", C.c_uint32 * 4)]
 
@@ -69,6 +69,10 @@ def lib():
     l.gsr_workspace_bytes.argtypes = [i32, i32, i32, i64]
     l.gsr_workspace_bytes_forward_only.restype = sz
     l.gsr_workspace_bytes_forward_only.argtypes = [i32, i32, i32, i64]
+    l.gsr_workspace_bytes_ex.restype = sz
+    l.gsr_workspace_bytes_ex.argtypes = [i32, i32, i32, i64, u32, i32]
+    l.gsr_direct_lists_ok.restype = i32
+    l.gsr_direct_lists_ok.argtypes = [i32, i32, u32]
     l.gsr_forward.restype = i32
     l.gsr_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, sz, i64, u32, vp]
     l.gsr_forward_notify.restype = i32
@@ -85,9 +89,9 @@ def lib():
     l.gsr_read_header.restype = i32
     l.gsr_read_header.argtypes = [vp, C.POINTER(GsrHeader), vp]
     l.gsr_export_state.restype = i32
-    l.gsr_export_state.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    l.gsr_export_state.argtypes = [vp, i32, i32, i32, i64, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     l.gsr_debug_count_records.restype = i32
-    l.gsr_debug_count_records.argtypes = [vp, sz, i32, i32, i32, i64, vp, vp]
+    l.gsr_debug_count_records.argtypes = [vp, sz, i32, i32, i32, i64, u32, vp, vp]
     l.gsr_mark_visible.restype = i32
     l.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     l.gsr_selftest.restype = i32

@@ -67,7 +67,7 @@ struct StageTimer {  // RAII: records an event pair around one stage when timing
     }
 };
 
-__global__ void k_export(int P, int T, const GsrSplat *__restrict__ splats, const uint32_t *__restrict__ tile_offset, float *depth,
+__global__ void k_export(int P, int T, const GsrSplat *__restrict__ splats, GsrBins bins, float *depth,
                          float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges) {  // T = number of bins
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < P) {
@@ -78,19 +78,23 @@ __global__ void k_export(int P, int T, const GsrSplat *__restrict__ splats, cons
         if (rect) { rect[4 * i] = s.bin_lo & 0xffff; rect[4 * i + 1] = s.bin_lo >> 16; rect[4 * i + 2] = s.bin_hi & 0xffff; rect[4 * i + 3] = s.bin_hi >> 16; }
     }
     if (i < T && tile_ranges) {
-        const uint32_t a = tile_offset[i], b = tile_offset[i + 1];
+        uint32_t a, b;
+        gsr_bin_range(bins, (uint32_t)i, a, b);
         tile_ranges[2 * i] = b > a ? (int64_t)a : 0;
         tile_ranges[2 * i + 1] = b > a ? (int64_t)b : 0;
     }
 }
 
 // GPSGS_TRACE only: after the sort, every entry of every bin list must be a Gaussian of the view and the lists must be in key order
-__global__ void k_validate_lists(int P, int NB, const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ bin_cursor, const uint32_t *__restrict__ point_list,
+__global__ void k_validate_lists(int P, int NB, GsrBins bins, const uint32_t *__restrict__ bin_cursor, const uint32_t *__restrict__ point_list,
                                  const GsrSplat *__restrict__ splats, unsigned long long *__restrict__ out) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= NB) return;
-    const uint32_t r0 = bin_offset[b], r1 = bin_offset[b + 1];
-    if (bin_cursor[(size_t)b * GSR_CPAD] != r1) atomicAdd(out + 4, 1ull);  // the scatter pass filled exactly the slots the count pass reserved
+    uint32_t r0, r1;
+    gsr_bin_range(bins, (uint32_t)b, r0, r1);
+    // scanned lists: the scatter pass filled exactly the slots the count pass reserved (direct lists have no second pass: a slot nobody wrote shows
+    // up below as an id that is not a Gaussian of the view, or out of order)
+    if (!bins.cap && bin_cursor[(size_t)b * GSR_CPAD] != r1) atomicAdd(out + 4, 1ull);
     unsigned long long bad_id = 0, bad_order = 0, bad_rec = 0;
     uint64_t prev = 0;
     for (uint32_t k = r0; k < r1; k++) {
@@ -138,6 +142,20 @@ extern "C" size_t gsr_workspace_bytes(int P, int width, int height, int64_t inst
     return gsr_layout(P, width, height, instance_capacity).total;
 }
 
+extern "C" int gsr_direct_lists_ok(int width, int height, uint32_t bin_capacity) {
+    if (width <= 0 || height <= 0 || bin_capacity == 0u || bin_capacity > GSR_DIRECT_MAX_CAP || (bin_capacity & 63u)) return 0;
+    const GsrLayout L = gsr_layout(0, width, height, 0);
+    const int nt = ((L.bx + 7) / 8) * ((L.by + 7) / 8) * 64;
+    return (L.NB <= GSR_DIRECT_MAX_BINS && nt <= GSR_DIRECT_MAX_BINS) ? 1 : 0;
+}
+
+extern "C" size_t gsr_workspace_bytes_ex(int P, int width, int height, int64_t instance_capacity, uint32_t bin_capacity, int forward_only) {
+    if (P < 0 || width < 0 || height < 0 || instance_capacity < 0) return 0;
+    if (bin_capacity && !gsr_direct_lists_ok(width, height, bin_capacity)) return 0;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity, bin_capacity);
+    return forward_only ? L.total_fwd : L.total;
+}
+
 extern "C" size_t gsr_workspace_bytes_forward_only(int P, int width, int height, int64_t instance_capacity) {
     if (P < 0 || width < 0 || height < 0 || instance_capacity < 0) return 0;
     return gsr_layout(P, width, height, instance_capacity).total_fwd;
@@ -159,7 +177,9 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     if (P > 0 && ((shs != nullptr) == (colors != nullptr) || (cov3D_precomp != nullptr) == (scales != nullptr && rotations != nullptr))) return GPSGS_E_INVALID;
     if (P > 0 && cov3D_precomp && (scales || rotations)) return GPSGS_E_INVALID;
     if (shs && (!ext->campos || ext->sh_degree > 3u || ext->sh_coeffs > 16u || (ext->sh_degree + 1u) * (ext->sh_degree + 1u) > ext->sh_coeffs)) return GPSGS_E_INVALID;
-    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    const uint32_t bin_cap = ext ? ext->bin_capacity : 0u;  // direct lists: a fixed-capacity segment per bin (GsrBins)
+    if (bin_cap && !gsr_direct_lists_ok(width, height, bin_cap)) return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity, bin_cap);
     if (workspace_bytes < L.total_fwd) return GPSGS_E_WORKSPACE;  // the backward tail is optional for a forward
     hipStream_t s = (hipStream_t)stream;
     uint32_t *host_hdr = nullptr;
@@ -210,6 +230,13 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     q.row_range = row_range;
     q.shs = shs; q.campos = shs ? ext->campos : nullptr; q.cov3D_precomp = cov3D_precomp;
     q.sh_degree = shs ? ext->sh_degree : 0u; q.sh_coeffs = shs ? ext->sh_coeffs : 0u;
+    q.keys_direct = bin_cap ? keys : nullptr; q.bin_cap = bin_cap;
+    {
+        const int nt = ((L.bx + 7) / 8) * ((L.by + 7) / 8) * 64;
+        const size_t nscan = (size_t)((nt > L.NB ? nt : L.NB) + 63) / 64;
+        q.arrive = bin_cap ? reinterpret_cast<uint32_t *>(at(workspace, L.scan_part + gsr_direct_arrive_offset(nscan))) : nullptr;
+    }
+    const GsrBins bins = {bin_offset, bin_count, bin_cap};
     // a workspace that includes the backward tail gets the per-Gaussian slot prefix and cleared record flags from the forward
     const bool training = workspace_bytes >= L.total;
     q.goff = training ? reinterpret_cast<uint32_t *>(at(workspace, L.goff)) : nullptr;
@@ -224,23 +251,32 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
         gsr_launch_preprocess(q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-    {
-        trace("scan", P, width, height, (long long)instance_capacity, flags);
-        StageTimer t(flags, GSR_STAGE_SCAN, s);
-        gsr_launch_scan(bin_count, bin_count_fb, bin_offset, bin_cursor, wg_order, scan_part, L.NB, L.bx, L.by, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
-                        (flags & GSR_FLAG_NO_LARGE_SORT) != 0, order_hint, s);
-    }
-    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-    {
-        trace("scatter", P, width, height, (long long)instance_capacity, flags);
-        StageTimer t(flags, GSR_STAGE_SCATTER, s);
-        gsr_launch_scatter(P, row_range, L.bx, splats, binrec, wg_tab, bin_offset, bin_cursor, keys, hdr, q.goff, q.gpart, inst_valid_fwd, s);
-    }
-    if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-    {
-        trace("sort", P, width, height, (long long)instance_capacity, flags);
+    if (bin_cap) {
+        // direct lists: k_preprocess has placed the keys; ONE more launch publishes the header (its first wave, also towards the host), sorts every bin's
+        // segment and, in its first workgroups, produces the work order and the slot prefix -- no scan in front of a scatter, no scatter
+        trace("sort+scan (direct lists)", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_SORT, s);
-        gsr_launch_sort(L.NB, bin_offset, wg_order, keys, point_list, hdr, (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
+        gsr_launch_sort_direct(L.NB, L.bx, L.by, bin_count, bin_cap, wg_order, scan_part, keys, point_list, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
+                               order_hint, s);
+    } else {
+        {
+            trace("scan", P, width, height, (long long)instance_capacity, flags);
+            StageTimer t(flags, GSR_STAGE_SCAN, s);
+            gsr_launch_scan(bin_count, bin_count_fb, bin_offset, bin_cursor, wg_order, scan_part, L.NB, L.bx, L.by, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
+                            (flags & GSR_FLAG_NO_LARGE_SORT) != 0, order_hint, s);
+        }
+        if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+        {
+            trace("scatter", P, width, height, (long long)instance_capacity, flags);
+            StageTimer t(flags, GSR_STAGE_SCATTER, s);
+            gsr_launch_scatter(P, row_range, L.bx, splats, binrec, wg_tab, bin_offset, bin_cursor, keys, hdr, s);
+        }
+        if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+        {
+            trace("sort", P, width, height, (long long)instance_capacity, flags);
+            StageTimer t(flags, GSR_STAGE_SORT, s);
+            gsr_launch_sort(L.NB, bin_offset, wg_order, keys, point_list, hdr, (flags & GSR_FLAG_NO_LARGE_SORT) != 0, s);
+        }
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     if (trace_on() || (flags & GSR_FLAG_DEBUG)) {  // self-check between the sort and the compositing (synchronises; never in normal operation)
@@ -262,7 +298,7 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
         if (hipMemcpyAsync(&h, hdr, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemsetAsync(d_out, 0, sizeof(h_out), s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
             return GPSGS_E_LAUNCH;
-        if (!h.overflow) hipLaunchKernelGGL(k_validate_lists, dim3((L.NB + 255) / 256), dim3(256), 0, s, P, L.NB, bin_offset, bin_cursor, point_list, splats, d_out);
+        if (!h.overflow) hipLaunchKernelGGL(k_validate_lists, dim3((L.NB + 255) / 256), dim3(256), 0, s, P, L.NB, bins, bin_cursor, point_list, splats, d_out);
         if (hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return GPSGS_E_LAUNCH;
         const bool bad = h_out[0] || h_out[1] || h_out[4];
         if (trace_on() || bad) {
@@ -277,9 +313,10 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
         trace("composite_fwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
         if (flags & GSR_FLAG_COMPOSITE_TILES)
-            gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, training, (flags & GSR_FLAG_WAVE_PRIORITY) != 0, s);
+            gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bins, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, inst_valid_fwd, training,
+                                           (flags & GSR_FLAG_WAVE_PRIORITY) != 0, s);
         else
-            gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, s);
+            gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bins, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, inst_valid_fwd, s);
     }
     return check(s, flags);
 }
@@ -316,11 +353,13 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
     if (cov3D_precomp ? (!ext->dL_dcov3D || scales || rotations) : (!scales || !rotations || !dL_dscales || !dL_drotations)) return GPSGS_E_INVALID;
     if (shs && (!ext->campos || !ext->dL_dsh || ext->sh_degree > 3u || ext->sh_coeffs > 16u || (ext->sh_degree + 1u) * (ext->sh_degree + 1u) > ext->sh_coeffs))
         return GPSGS_E_INVALID;
-    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    const uint32_t bin_cap = ext ? ext->bin_capacity : 0u;  // must be what the forward was given
+    if (bin_cap && !gsr_direct_lists_ok(width, height, bin_cap)) return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity, bin_cap);
     if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const GsrHeader *hdr = reinterpret_cast<const GsrHeader *>(at(workspace, L.header));
-    const uint32_t *bin_offset = reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset));
+    const GsrBins bins = {reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count)), bin_cap};
     const uint32_t *wg_order = reinterpret_cast<const uint32_t *>(at(workspace, L.wg_order));
     const GsrSplat *splats = reinterpret_cast<const GsrSplat *>(at(workspace, L.splats));
     const uint32_t *point_list = reinterpret_cast<const uint32_t *>(at(workspace, L.point_list));
@@ -340,10 +379,10 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
         // must be the same family as the forward that filled the workspace: the two designs round the exponent differently, and the
         // backward has to repeat the forward's per-pixel decisions
         if (flags & GSR_FLAG_COMPOSITE_TILES)
-            gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr,
+            gsr_launch_composite_bwd_tiles(width, height, L.bx, L.by, splats, bins, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr,
                                            (flags & GSR_FLAG_NO_COLOR_GRAD) == 0, (flags & GSR_FLAG_WAVE_PRIORITY) != 0, s);
         else
-            gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bin_offset, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
+            gsr_launch_composite_bwd(width, height, L.bx, L.by, splats, bins, wg_order, point_list, bg, dL_dpix, final_T, n_contrib, goff, gscan_part, inst_valid, inst_dop, inst_grad, hdr, s);
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     GsrBwdParams b;
@@ -422,10 +461,11 @@ extern "C" int gpsgs_measure_sclk(unsigned long long *scratch3_device, double *m
 
 extern "C" int gsr_debug_set_wg_trace(unsigned long long *rows_device) { return gsr_set_wg_trace(rows_device) == 0 ? GPSGS_OK : GPSGS_E_LAUNCH; }
 
-extern "C" int gsr_debug_count_records(const void *workspace, size_t workspace_bytes, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device,
-                                       void *stream) {
+extern "C" int gsr_debug_count_records(const void *workspace, size_t workspace_bytes, int P, int width, int height, int64_t instance_capacity, uint32_t bin_capacity,
+                                       unsigned long long *out2_device, void *stream) {
     if (!workspace || !out2_device || P < 0 || width <= 0 || height <= 0 || instance_capacity < 0) return GPSGS_E_INVALID;
-    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    if (bin_capacity && !gsr_direct_lists_ok(width, height, bin_capacity)) return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity, bin_capacity);
     if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;  // a forward-only workspace has no record flags (they lie beyond its end)
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(out2_device, 0, 16, s) != hipSuccess) return GPSGS_E_LAUNCH;
@@ -460,19 +500,21 @@ extern "C" int gsr_read_header(const void *workspace, GsrHeader *host_out, void 
     return GPSGS_OK;
 }
 
-extern "C" int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, float *depth, float *xy,
+extern "C" int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, uint32_t bin_capacity, float *depth, float *xy,
                                 float *conic_opacity, int *rect, int64_t *tile_ranges, uint32_t *point_list, float *final_T,
                                 uint32_t *n_contrib, void *stream) {
     if (!workspace || P < 0 || width <= 0 || height <= 0) return GPSGS_E_INVALID;
-    const GsrLayout L = gsr_layout(P, width, height, instance_capacity);
+    if (bin_capacity && !gsr_direct_lists_ok(width, height, bin_capacity)) return GPSGS_E_INVALID;
+    const GsrLayout L = gsr_layout(P, width, height, instance_capacity, bin_capacity);
     hipStream_t s = (hipStream_t)stream;
     const int n = P > L.NB ? P : L.NB;
+    const GsrBins bins = {reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count)), bin_capacity};
     if (n > 0)
-        hipLaunchKernelGGL(k_export, dim3((n + 255) / 256), dim3(256), 0, s, P, L.NB, reinterpret_cast<const GsrSplat *>(at(workspace, L.splats)),
-                           reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), depth, xy, conic_opacity, rect, tile_ranges);
+        hipLaunchKernelGGL(k_export, dim3((n + 255) / 256), dim3(256), 0, s, P, L.NB, reinterpret_cast<const GsrSplat *>(at(workspace, L.splats)), bins, depth, xy,
+                           conic_opacity, rect, tile_ranges);
     const size_t npix = (size_t)width * height;
-    if (point_list && instance_capacity > 0)
-        (void)hipMemcpyAsync(point_list, at(workspace, L.point_list), (size_t)instance_capacity * 4, hipMemcpyDeviceToDevice, s);
+    if (point_list && L.key_cap > 0)  // point_list [key capacity]: the instance capacity, or bins x bin_capacity (direct lists: every bin's segment, gaps included)
+        (void)hipMemcpyAsync(point_list, at(workspace, L.point_list), (size_t)L.key_cap * 4, hipMemcpyDeviceToDevice, s);
     if (final_T) (void)hipMemcpyAsync(final_T, at(workspace, L.final_T), npix * 4, hipMemcpyDeviceToDevice, s);
     if (n_contrib) (void)hipMemcpyAsync(n_contrib, at(workspace, L.n_contrib), npix * 4, hipMemcpyDeviceToDevice, s);
     return hipGetLastError() == hipSuccess ? GPSGS_OK : GPSGS_E_LAUNCH;

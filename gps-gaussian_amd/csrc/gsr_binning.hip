@@ -260,8 +260,7 @@ constexpr int SC_THREADS = GSR_BIN_THREADS / SC_PER;     // threads of a scatter
 // (6 waves per SIMD: every workgroup of a 600 k-Gaussian view is resident at once)
 __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scatter(int P, const uint32_t *__restrict__ row_range, int bx, const GsrSplat *__restrict__ splats, const uint4 *__restrict__ binrec,
                                                        const uint32_t *__restrict__ wg_tab, const uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
-                                                       uint64_t *__restrict__ keys, const GsrHeader *__restrict__ hdr, const uint32_t *__restrict__ goff,
-                                                       const uint32_t *__restrict__ gpart, uint8_t *__restrict__ inst_valid) {
+                                                       uint64_t *__restrict__ keys, const GsrHeader *__restrict__ hdr) {
     __shared__ uint32_t s_cnt[GSR_BLOCK_TAB], s_base[GSR_BLOCK_TAB];
     __shared__ int s_box[4];
     // The kernel is a chain of memory round trips (round-5 counters: two thirds of its wave cycles are spent waiting): every load that depends on
@@ -281,8 +280,6 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
     for (int k = 0; k < TPT; k++) tent[k] = tab[4 + k * SC_THREADS + (int)threadIdx.x];
     const int tab_bx0 = (int)tab[0], tab_by0 = (int)tab[1], tab_bw = (int)tab[2], tab_bh = (int)tab[3];
-    const uint32_t s_beg = inst_valid ? gpart[blockIdx.x] : 0u;
-    const uint32_t s_nxt = inst_valid ? ((blockIdx.x + 1 < gridDim.x) ? gpart[blockIdx.x + 1] : hdr->num_slots) : 0u;
     if (hdr->overflow) return;
     {
         uint32_t row0;
@@ -299,17 +296,6 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         if (t < area && tent[k]) {
             const int ty = t / tab_bw, tx = t - ty * tab_bw;
             toff[k] = bin_offset[(tab_by0 + ty) * bx + tab_bx0 + tx];
-        }
-    }
-    if (inst_valid) {
-        // training: "no gradient record yet" for every slot of this workgroup's Gaussians (replaces a cap-byte memset).  Their slots are ONE
-        // contiguous run [gpart[blk], gpart[blk + 1]) -- cleared by the whole workgroup with 16-byte stores.
-        for (uint32_t k = (s_beg & ~15u) + (uint32_t)threadIdx.x * 16u; k < s_nxt; k += SC_THREADS * 16u) {
-            if (k >= s_beg && k + 16u <= s_nxt) {
-                *reinterpret_cast<uint4 *>(inst_valid + k) = make_uint4(0u, 0u, 0u, 0u);
-            } else {
-                for (uint32_t b = (k > s_beg ? k : s_beg); b < k + 16u && b < s_nxt; b++) inst_valid[b] = 0;
-            }
         }
     }
     uint32_t lo[SC_PER], hi[SC_PER], mask[SC_PER];
@@ -341,7 +327,7 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
             const uint64_t k64 = key[u];
             auto res = [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); };
             gsr_block_bin<true, SC_THREADS>(s_cnt, s_base, s_box, lo[u], hi[u], bx, gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]), res, res,
-                                            [&](uint32_t pos, uint32_t) { keys[pos] = k64; });
+                                            [&](uint32_t pos, uint32_t, uint32_t) { keys[pos] = k64; });
         }
         return;
     }
@@ -362,7 +348,7 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
     for (int u = 0; u < SC_PER; u++) {
         const uint64_t k64 = key[u];
-        gsr_block_emit_one(s_cnt, s_base, tab_bx0, tab_by0, tab_bw, lo[u], hi[u], gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]), [&](uint32_t pos, uint32_t) { keys[pos] = k64; });
+        gsr_block_emit_one(s_cnt, s_base, tab_bx0, tab_by0, tab_bw, bx, lo[u], hi[u], gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]), [&](uint32_t pos, uint32_t, uint32_t) { keys[pos] = k64; });
     }
 }
 
@@ -697,18 +683,8 @@ __device__ __forceinline__ bool sort_wave_regs32(const uint64_t *__restrict__ se
     return true;
 }
 
-// lists of 1..1024 keys (the common case: a body bin holds ~450): ONE WAVE per bin, keys in registers.
-__global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
-                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
-                                                  const GsrHeader *__restrict__ hdr) {
-    const uint32_t bin = wg_order[blockIdx.x];  // busy bins first (requested together with the header: one round trip, not two)
-    if (hdr->overflow || blockIdx.x >= hdr->num_busy_wgs) return;
-    const uint32_t off = bin_offset[bin], n = bin_offset[bin + 1] - off;
-    if (n == 0 || n > 1024u) return;
-    const uint64_t *seg = keys + off;
-    uint32_t *out = point_list + off;
-    const int lane = threadIdx.x;
-    __shared__ uint32_t ids[1024];
+// one list of 1..1024 keys sorted by ONE wave, keys in registers (ids: 1,024 words of LDS)
+__device__ __forceinline__ void sort_wave_list(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, uint32_t *ids, int lane) {
     if (n == 1u) { if (lane == 0) out[0] = (uint32_t)seg[0]; return; }
     bool done;
     if (n <= 64u) done = sort_wave_regs32<1>(seg, n, out, ids, lane);
@@ -722,6 +698,155 @@ __global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ b
     else if (n <= 256u) sort_wave_regs<4>(seg, n, out, lane);
     else if (n <= 512u) sort_wave_regs<8>(seg, n, out, lane);
     else sort_wave_regs<16>(seg, n, out, lane);
+}
+
+// lists of 1..1024 keys (the common case: a body bin holds ~450): ONE WAVE per bin, keys in registers.
+__global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                                                  const GsrHeader *__restrict__ hdr) {
+    const uint32_t bin = wg_order[blockIdx.x];  // busy bins first (requested together with the header: one round trip, not two)
+    if (hdr->overflow || blockIdx.x >= hdr->num_busy_wgs) return;
+    const uint32_t off = bin_offset[bin], n = bin_offset[bin + 1] - off;
+    if (n == 0 || n > 1024u) return;
+    __shared__ uint32_t ids[1024];
+    sort_wave_list(keys + off, n, point_list + off, ids, (int)threadIdx.x);
+}
+
+// ---- DIRECT lists (GsrBins::cap > 0; round 6): the sort launch carries the scan ------------------------------------------------------------------------
+// With a fixed-capacity segment per bin nothing downstream needs the exclusive scan of the counts any more.  What is left of k_scan_b: the totals
+// (R, longest list, overflow) and the header, also towards the host -- k_preprocess' workgroups accumulate them in a few sharded counters as they go
+// and the FIRST wave of this launch publishes them, so the host learns them about as early as with scanned lists -- and the work order of the
+// compositing waves + the slot prefix of the gradient records.  Neither of the latter is needed by the sort, so they ride in the sort's launch: workgroups [0, nscan) (one wave each, 64 indices of the patch order
+// per wave) do the scan work -- they exchange their partials as self-validating 64-bit words like k_scan_b's blocks (no fences) -- while workgroups
+// nscan + b sort bin b.  The sorting waves never wait for anything, so the polling scan waves cannot deadlock whatever the dispatch order (<= 1,024
+// of them: GSR_DIRECT_MAX_BINS; they are the first workgroups of the grid and in practice all resident before the first sort wave).  The forward
+// chain is then k_preprocess (count + scatter) -> this launch -> compositing: three dependent launches instead of five (zero, preprocess, scan,
+// scatter, sort), and the 10 us latency chain of the scan overlaps the sort instead of preceding the scatter.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+__device__ __forceinline__ unsigned long long poll_word(unsigned long long *w) {
+    unsigned long long v;
+    while (((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull) __builtin_amdgcn_s_sleep(1);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_sort_direct(int nscan, int NB, int bx, int by, const uint32_t *__restrict__ bin_count, uint32_t bin_cap,
+                                                    uint32_t *__restrict__ wg_order, unsigned long long *__restrict__ part /* 1 word per scan workgroup */,
+                                                    const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                                                    GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks, uint32_t hint,
+                                                    const uint32_t *__restrict__ shards, int64_t slot_cap, uint32_t *__restrict__ host_hdr, uint32_t host_seq) {
+    __shared__ uint32_t ids[1024];
+    const int lane = threadIdx.x;
+    if (blockIdx.x == 0) {
+        // the view's totals, first thing in the launch: k_preprocess' workgroups left {instances | slots << 32, longest list} in GSR_ARRIVE_SHARDS
+        // accumulators; they become the header -- and the host's early capacity notification, ~3 us behind the end of k_preprocess
+        unsigned long long acc = 0ull;
+        uint32_t mx = 0u;
+        if (lane < GSR_ARRIVE_SHARDS) {
+            acc = *reinterpret_cast<const unsigned long long *>(shards + 16 * lane);
+            mx = shards[16 * lane + 2];
+        }
+        uint32_t inst = (uint32_t)acc, slots = (uint32_t)(acc >> 32);
+        unsigned long long tsum = inst;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            tsum += (unsigned long long)__shfl_xor((long long)tsum, d, 64);
+            slots += (uint32_t)__shfl_xor((int)slots, d, 64);
+            const uint32_t y = (uint32_t)__shfl_xor((int)mx, d, 64);
+            mx = y > mx ? y : mx;
+        }
+        if (lane == 0) {
+            // a list longer than the bins' capacity is reported like an overflow (max_tile_count > capacity tells the caller which): nothing is composited
+            const bool ovf_b = mx > bin_cap || (int64_t)slots > slot_cap || hdr->row_overflow != 0u;
+            hdr->num_rendered = tsum;
+            hdr->overflow = ovf_b ? 1u : 0u;
+            hdr->max_tile_count = mx;
+            hdr->num_slots = slots;
+            if (host_hdr) {  // as k_scan_b: write-through stores, acknowledged, then the sequence word the host polls
+                const uint32_t hv[7] = {(uint32_t)tsum, (uint32_t)(tsum >> 32), ovf_b ? 1u : 0u, mx, 0u /* busy bins: known at the end of this launch */, slots, hdr->num_points};
+#pragma unroll
+                for (int k = 0; k < 7; k++) __hip_atomic_store(host_hdr + k, hv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_amdgcn_s_waitcnt(0);
+                __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if ((int)blockIdx.x >= nscan) {  // ---- a sorting wave
+        const uint32_t bin = blockIdx.x - (uint32_t)nscan;
+        const uint32_t cnt = bin_count[bin];
+        const uint32_t n = cnt < bin_cap ? cnt : bin_cap;  // (a longer list is an overflow: the first wave of this launch reports it, nothing is composited)
+        if (n == 0u) return;
+        const size_t off = (size_t)bin * bin_cap;
+        sort_wave_list(keys + off, n, point_list + off, ids, lane);
+        return;
+    }
+    // ---- a scan wave: 64 indices of the patch order -> their places in the work order
+    const int blk = blockIdx.x;
+    const int b = blk * 64 + lane;
+    const int wb = gsr_tiled_bin((uint32_t)b, bx, by);
+    const uint32_t wc = wb >= 0 ? bin_count[wb] : 0u;
+    const int cls = gsr_work_class(wb, wc, hint);
+    const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+    if (lane == 0) {  // class counts <= 64: 7 bits each, + the ready bit: one self-validating word
+        const unsigned long long A = (unsigned long long)__popcll(m0) | ((unsigned long long)__popcll(m1) << 7) | ((unsigned long long)__popcll(m2) << 14) |
+                                     ((unsigned long long)__popcll(m3) << 21) | (1ull << 63);
+        __hip_atomic_store(part + blk, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the slot prefix of the gradient records (training): one scan wave (the second, when there is one) turns the per-block slot counts k_preprocess
+    // left into their exclusive prefix, in place
+    if (gpart && blk == (nscan > 1 ? 1 : 0)) {
+        uint32_t carry = 0u;
+        for (int base = 0; base < n_gblocks; base += 64 * 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {  // eight independent loads in flight, then eight wave scans
+                const int k = base + u * 64 + lane;
+                v[u] = k < n_gblocks ? gpart[k] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = base + u * 64 + lane;
+                const uint32_t x = wave_incl_scan(v[u], lane);
+                if (k < n_gblocks) gpart[k] = carry + x - v[u];
+                carry += (uint32_t)__shfl((int)x, 63, 64);
+            }
+        }
+    }
+    // every scan wave needs the class totals of all of them and the prefix of those in front of it
+    uint32_t t[4] = {0u, 0u, 0u, 0u}, pre[4] = {0u, 0u, 0u, 0u};
+    for (int i0 = 0; i0 < nscan; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < nscan) {
+            const unsigned long long A = poll_word(part + i);
+            const uint32_t n0 = (uint32_t)A & 0x7fu, n1 = (uint32_t)(A >> 7) & 0x7fu, n2 = (uint32_t)(A >> 14) & 0x7fu, n3 = (uint32_t)(A >> 21) & 0x7fu;
+            t[0] += n0; t[1] += n1; t[2] += n2; t[3] += n3;
+            if (i < blk) { pre[0] += n0; pre[1] += n1; pre[2] += n2; pre[3] += n3; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            t[k] += (uint32_t)__shfl_xor((int)t[k], d, 64);
+            pre[k] += (uint32_t)__shfl_xor((int)pre[k], d, 64);
+        }
+    }
+    const uint32_t tot_busy = t[0] + t[1] + t[2];
+    if (blk == 0 && lane == 0) hdr->num_busy_wgs = tot_busy;
+    // work order: the classes in order (longest lists first, idle bins last), patch order inside a class
+    if (wb >= 0) {
+        const unsigned long long mine = cls == 0 ? m0 : cls == 1 ? m1 : cls == 2 ? m2 : m3;
+        const uint32_t r = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+        const uint32_t pos = cls == 0 ? pre[0] + r : cls == 1 ? t[0] + pre[1] + r : cls == 2 ? t[0] + t[1] + pre[2] + r : tot_busy + pre[3] + r;
+        wg_order[pos] = (uint32_t)wb;
+    }
 }
 
 // ---- lists of 1,025 .. 8,192 keys: 1 / 2 / 4 waves per list, 32 keys per lane in registers -------------------------------------------
@@ -925,10 +1050,10 @@ void gsr_launch_scan(const uint32_t *bin_count, const uint32_t *bin_count_fb, ui
 }
 
 void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_offset,
-                        uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s) {
+                        uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s) {
     if (P <= 0) return;
     hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(SC_THREADS), 0, s, P, row_range, bx, splats, binrec, wg_tab, bin_offset, bin_cursor, keys,
-                       hdr, goff, gpart, inst_valid);
+                       hdr);
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
@@ -950,4 +1075,15 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
     hipLaunchKernelGGL(k_sort_multi<2>, dim3(busy_max < 8192 ? busy_max : 8192), dim3(128), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_multi<1>, dim3(busy_max < g1 ? busy_max : g1), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 1024 ? NB : 1024), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
+}
+
+void gsr_launch_sort_direct(int NB, int bx, int by, const uint32_t *bin_count, uint32_t bin_cap, uint32_t *wg_order, uint4 *scan_part, uint64_t *keys,
+                            uint32_t *point_list, int64_t slot_cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq,
+                            uint32_t order_hint, hipStream_t s) {
+    if (NB <= 0) return;
+    const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB)
+    const int nscan = ((NT > NB ? NT : NB) + 63) / 64;
+    const uint32_t *shards = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(scan_part) + gsr_direct_arrive_offset((size_t)nscan));
+    hipLaunchKernelGGL(k_sort_direct, dim3(nscan + NB), dim3(64), 0, s, nscan, NB, bx, by, bin_count, bin_cap, wg_order, reinterpret_cast<unsigned long long *>(scan_part), keys,
+                       point_list, hdr, gpart, n_gblocks, order_hint, shards, slot_cap, host_hdr, host_seq);
 }

@@ -73,8 +73,21 @@ struct __attribute__((aligned(32))) GsrGradAcc {
 };                            // dL/dopacity lives in inst_dop[]
 static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte sector");
 
+// Per-bin list ranges as the kernels behind the binning see them.  Two forms (GsrViewExt.bin_capacity):
+//   scanned lists (cap == 0): bin b owns [offset[b], offset[b + 1]) of keys / point_list -- the exclusive scan of the counts (k_scan_b);
+//   DIRECT lists (cap > 0, round 6): bin b owns [b * cap, b * cap + count[b]) -- a fixed-capacity segment per bin, so that an instance's slot is known
+//     the moment k_preprocess' count atomic returns: the scatter pass runs inside k_preprocess, k_scatter and its tables disappear, and the scan (which
+//     still produces the work order and the header) leaves the critical path (it rides in the sort launch).  A view whose longest list exceeds cap is
+//     reported as an overflow (header.max_tile_count > cap) and the caller repeats it with scanned lists.
+struct GsrBins {
+    const uint32_t *offset, *count;
+    uint32_t cap;
+};
+
 struct GsrLayout {
     size_t header, bin_count, bin_count_fb, bin_offset, bin_cursor, wg_order, scan_part, splats, binrec, wg_tab, keys, point_list, final_T, n_contrib;
+    uint32_t bin_cap;  // 0: scanned lists; else the per-bin capacity of direct lists
+    int64_t key_cap;   // entries of keys / point_list: the instance capacity, or NB * bin_cap
     size_t total_fwd;  // bytes a forward-only workspace needs
     size_t goff, gscan_part, inst_valid, inst_dop, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
@@ -86,9 +99,12 @@ struct GsrLayout {
 };
 
 static inline size_t gsr_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+#define GSR_ARRIVE_SHARDS 32
+static inline size_t gsr_direct_arrive_offset(size_t nscan) { return ((nscan + 1) * 8 + 127) & ~(size_t)127; }  // inside the scan_part section
 
-static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
+static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap, uint32_t bin_cap = 0u) {
     GsrLayout L;
+    L.bin_cap = bin_cap;
     L.gx = (W + GSR_TILE - 1) / GSR_TILE;
     L.gy = (H + GSR_TILE - 1) / GSR_TILE;
     L.bx_real = (W + GSR_BIN - 1) / GSR_BIN;
@@ -104,17 +120,25 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
     const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.NB > 0 ? L.NB : 1), c = (size_t)(cap > 0 ? cap : 1);
     const size_t npix = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
     L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + scan_part + bin_count + bin_count_fb are zeroed by ONE memset
-    L.scan_part = o;  o = gsr_align_up(o + ((size_t)L.NSB + 1) * 32);  // two 64-bit words per scan block (+ padding)
+    {   // two 64-bit words per scan block (+ padding); direct lists: two per scan WAVE of the sort launch (64 patch-order indices each) + one
+        const size_t nt = (size_t)((L.bx + 7) / 8) * ((L.by + 7) / 8) * 64;
+        const size_t nscan = ((nt > t ? nt : t) + 63) / 64;
+        // direct lists: one word per scan wave, then (128-byte aligned) the total accumulators of k_preprocess' workgroups, GSR_ARRIVE_SHARDS x 64 bytes
+        const size_t a = ((size_t)L.NSB + 1) * 32, b = bin_cap ? gsr_direct_arrive_offset(nscan) + GSR_ARRIVE_SHARDS * 64 : 0;
+        L.scan_part = o;  o = gsr_align_up(o + (a > b ? a : b));
+    }
     L.bin_count = o;  o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.bin_count_fb = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);  // instances counted by workgroups whose bins do not fit the LDS table (see gsr_block_bin)
     L.bin_offset = o; o = gsr_align_up(o + (t + 1) * 4);
     L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
-    L.binrec = o;     o = gsr_align_up(o + p * 16);
-    L.wg_tab = o;     o = gsr_align_up(o + ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
-    L.keys = o;       o = gsr_align_up(o + c * 8);
-    L.point_list = o; o = gsr_align_up(o + c * 4);
+    // (binrec / wg_tab carry the count pass' decisions to k_scatter: direct lists have no scatter pass)
+    L.binrec = o;     o = gsr_align_up(o + (bin_cap ? 1 : p) * 16);
+    L.wg_tab = o;     o = gsr_align_up(o + (bin_cap ? 1 : ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS)) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
+    L.key_cap = bin_cap ? (int64_t)t * (int64_t)bin_cap : (int64_t)c;
+    L.keys = o;       o = gsr_align_up(o + (size_t)L.key_cap * 8);
+    L.point_list = o; o = gsr_align_up(o + (size_t)L.key_cap * 4);
     L.final_T = o;    o = gsr_align_up(o + npix * 4);
     L.n_contrib = o;  o = gsr_align_up(o + npix * 4);
     L.total_fwd = o;
@@ -128,13 +152,24 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap) {
 }
 
 #if defined(__HIPCC__)
+__device__ __forceinline__ void gsr_bin_range(const GsrBins &b, uint32_t bin, uint32_t &r0, uint32_t &r1) {
+    if (b.cap) {  // (kernel-argument uniform)
+        const uint32_t n = b.count[bin];
+        r0 = bin * b.cap;
+        r1 = r0 + (n < b.cap ? n : b.cap);  // (a longer list is an overflow: nothing behind the scan runs; the clamp only keeps a debug read inside its segment)
+    } else {
+        r0 = b.offset[bin];
+        r1 = b.offset[bin + 1];
+    }
+}
+
 // Workgroup-aggregated binning.  Same-address device atomics serialise at ~0.1-0.2 us each on MI355X (measured,
 // tools/ubench/atomic_bench*.hip), and a body bin receives ~450 instances, so per-instance -- or even per-wave --
 // atomics on the per-bin counters cost >100 us.  Pixel-Gaussians arrive in source-raster order, so the bins touched
 // by one 1024-thread workgroup form a small rectangle of the bin grid: the workgroup histograms its instances into a
 // direct-indexed LDS table over that rectangle (ds_add, which also hands every instance its rank) and then issues ONE
-// global atomic per touched bin (reserve(bin, count) -> base).  emit(pos, cell) is called once per instance with its slot
-// and the row-major index of the bin inside the Gaussian's own bin rect.
+// global atomic per touched bin (reserve(bin, count) -> base).  emit(pos, cell, bin) is called once per instance with its slot,
+// the row-major index of the bin inside the Gaussian's own bin rect, and the bin.
 // Incoherent input (bounding rectangle > GSR_BLOCK_TAB bins) falls back to one global atomic per instance.
 
 // Exact (Gaussian, bin) culling inside the bin rect.  alpha = op*exp(-q/2) >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2
@@ -351,7 +386,7 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t *s_cnt, uint32_t *s_base,
                         for (int x = xa; x < xb; x++) {
                             if (!hit(x, y)) continue;
                             const int t = (y - yb) * bw + (x - bx0);
-                            emit(s_base[t] + atomicAdd(&s_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
+                            emit(s_base[t] + atomicAdd(&s_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)), (uint32_t)(y * bx + x));
                         }
                     }
             }
@@ -366,7 +401,7 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t *s_cnt, uint32_t *s_base,
                 for (int x = xa; x < xb; x++) {
                     if (!hit(x, y)) continue;
                     const uint32_t pos = reserve_fb(y * bx + x, 1u);
-                    if (EMIT) emit(pos, (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
+                    if (EMIT) emit(pos, (uint32_t)((y - y0) * (x1 - x0) + (x - x0)), (uint32_t)(y * bx + x));
                 }
             }
         return;
@@ -400,13 +435,13 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t *s_cnt, uint32_t *s_base,
             for (int x = xa; x < xb; x++) {
                 if (!hit(x, y)) continue;
                 const int t = (y - by0) * bw + (x - bx0);
-                emit(s_base[t] + atomicAdd(&s_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
+                emit(s_base[t] + atomicAdd(&s_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)), (uint32_t)(y * bx + x));
             }
         }
 }
 // Scatter pass from the recorded table (k_scatter sets the tables up itself): per Gaussian, rank inside the workgroup by LDS atomic, then emit.
 template <typename Hit, typename Emit>
-__device__ __forceinline__ void gsr_block_emit_one(uint32_t *e_cnt, const uint32_t *e_base, int bx0, int by0, int bw, uint32_t lo, uint32_t hi, Hit hit, Emit emit) {
+__device__ __forceinline__ void gsr_block_emit_one(uint32_t *e_cnt, const uint32_t *e_base, int bx0, int by0, int bw, int bx, uint32_t lo, uint32_t hi, Hit hit, Emit emit) {
     const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
     if ((x1 > x0) && (y1 > y0))
         for (int y = y0; y < y1; y++) {
@@ -415,7 +450,7 @@ __device__ __forceinline__ void gsr_block_emit_one(uint32_t *e_cnt, const uint32
             for (int x = xa; x < xb; x++) {
                 if (!hit(x, y)) continue;
                 const int t = (y - by0) * bw + (x - bx0);
-                emit(e_base[t] + atomicAdd(&e_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)));
+                emit(e_base[t] + atomicAdd(&e_cnt[t], 1u), (uint32_t)((y - y0) * (x1 - x0) + (x - x0)), (uint32_t)(y * bx + x));
             }
         }
 }
@@ -436,6 +471,11 @@ struct GsrFwdParams {
     const float *shs, *campos, *cov3D_precomp;  // [rows, sh_coeffs, 3], [3], [rows, 6]; NULL = not used
     uint32_t sh_degree, sh_coeffs;
     float fx, fy;  // focal lengths in pixels, W / (2 tanfovx): set by gsr_launch_preprocess (two IEEE divisions per THREAD of a VALU-bound kernel otherwise)
+    // direct lists (GsrBins::cap > 0): k_preprocess drops the keys into the bins' fixed-capacity segments itself and accumulates the view's totals
+    // (instances, slots, longest list) in `arrive`: GSR_ARRIVE_SHARDS accumulators {u64 instances | slots << 32, u32 longest}, 64 bytes apart, zeroed with the header
+    uint64_t *keys_direct;
+    uint32_t bin_cap;
+    uint32_t *arrive;
 };
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binrec, uint32_t *wg_tab, uint32_t *bin_count, uint32_t *bin_count_fb, GsrHeader *hdr,
@@ -445,12 +485,21 @@ void gsr_launch_scan(const uint32_t *bin_count, const uint32_t *bin_count_fb, ui
                      int by, int64_t cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq, bool no_large_sort, uint32_t order_hint,
                      hipStream_t s);
 void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_offset,
-                        uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, hipStream_t s);
+                        uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s);
-void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
-                              const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr, hipStream_t s);
-void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+// direct lists: ONE launch sorts every bin's segment (one wave per bin, n <= bin_cap <= 1024) and, in its first workgroups, does what is left of
+// k_scan_b's work -- the work order of the compositing waves and the slot prefix of the gradient records (the totals and the header were published
+// by the last workgroup of k_preprocess)
+void gsr_launch_sort_direct(int NB, int bx, int by, const uint32_t *bin_count, uint32_t bin_cap, uint32_t *wg_order, uint4 *scan_part, uint64_t *keys,
+                            uint32_t *point_list, int64_t slot_cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq,
+                            uint32_t order_hint, hipStream_t s);
+#define GSR_DIRECT_MAX_BINS 65536  // direct lists: the scan workgroups of the sort launch poll each other's partials (all resident: <= 1,024 of them)
+#define GSR_DIRECT_MAX_CAP 1024    // ... and a bin's list is sorted by ONE wave (k_sort_wave's classes)
+void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
+                              const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr,
+                              uint8_t *inst_valid /* training workspace: the record flags are cleared here; NULL otherwise */, hipStream_t s);
+void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
                               const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop, GsrGradAcc *inst_grad, const GsrHeader *hdr,
                               hipStream_t s);
@@ -463,12 +512,13 @@ static inline unsigned gsr_debug_lds_pad() {
     return (unsigned)v;
 }
 // exponents from bf16 matrix-core tiles (gsr_composite_tiles.hip): same arguments, same results within rounding
-void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr,
+                                    uint8_t *inst_valid /* training workspace: the record flags are cleared here; NULL otherwise */,
                                     bool keep_state /* false: inference workspace, final_T / n_contrib are not produced */,
                                     bool wave_prio /* GSR_FLAG_WAVE_PRIORITY */, hipStream_t s);
 int gsr_set_wg_trace(unsigned long long *rows_device);  // development aid: per-workgroup timeline of the tile compositing kernels (NULL = off)
-void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,
                                     const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop, GsrGradAcc *inst_grad, const GsrHeader *hdr,
                                     bool color_grad /* false: GSR_FLAG_NO_COLOR_GRAD, the colour sums are left out (zeros in the records) */,

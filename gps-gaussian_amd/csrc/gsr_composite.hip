@@ -26,19 +26,20 @@
 namespace {
 
 __global__ __launch_bounds__(64 * WAVES) void k_composite_fwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
-                                                       const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                       GsrBins bins, const uint32_t *__restrict__ wg_order,
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        float *__restrict__ out_color, float *__restrict__ final_T,
-                                                       uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr) {
+                                                       uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr, uint8_t *__restrict__ inst_valid) {
     __shared__ float4 sA[WAVES][WAVE];
     __shared__ float4 sB[WAVES][WAVE];
     __shared__ float sC[WAVES][WAVE];
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
-    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    const WaveGeom g = wave_geom(W, H, bx, bins, wg_order, list_pos);
     if (hdr->overflow) {  // nothing can be rendered from truncated lists: a deterministic zero image instead of uninitialised memory
         fwd_write_blank(g, W, H, out_color, final_T, n_contrib);
         return;
     }
+    clear_record_flags(inst_valid, hdr, (int)threadIdx.x, 64 * WAVES);
     const float pxf = (float)g.px, pyf = (float)g.py;
     float4 *wA = sA[g.wid], *wB = sB[g.wid];
     float *wC = sC[g.wid];
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_fwd(int W, int H, int 
 }
 
 __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int bx, const GsrSplat *__restrict__ splats,
-                                                       const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                       GsrBins bins, const uint32_t *__restrict__ wg_order,
                                                        const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                        const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
                                                        const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
     if (hdr->overflow) return;
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     if (list_pos >= hdr->num_busy_wgs) return;  // idle workgroups sit at the end of wg_order
-    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    const WaveGeom g = wave_geom(W, H, bx, bins, wg_order, list_pos);
     if (g.r1 <= g.r0) return;
     const int lane = g.lane;
     const float pxf = (float)g.px, pyf = (float)g.py;
@@ -256,21 +257,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_composite_bwd(int W, int H, int 
 
 }  // namespace
 
-void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
-                              const GsrHeader *hdr, hipStream_t s) {
+                              const GsrHeader *hdr, uint8_t *inst_valid, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_fwd, dim3(wgs), dim3(64 * WAVES), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, out_color,
-                       final_T, n_contrib, hdr);
+    hipLaunchKernelGGL(k_composite_fwd, dim3(wgs), dim3(64 * WAVES), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list, bg, out_color,
+                       final_T, n_contrib, hdr, inst_valid);
 }
 
-void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+void gsr_launch_composite_bwd(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
                               const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop,
                               GsrGradAcc *inst_grad, const GsrHeader *hdr, hipStream_t s) {
     const int wgs = (bx / WAVES) * by;
     if (wgs <= 0) return;
-    hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(64 * WAVES), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg, dL_dpix,
+    hipLaunchKernelGGL(k_composite_bwd, dim3(wgs), dim3(64 * WAVES), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list, bg, dL_dpix,
                        final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }

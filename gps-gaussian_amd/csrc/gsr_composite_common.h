@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t xcd_list_pos(uint32_t w, uint32_t busy) {
     return (((q >> 6) << 3) + x) * 64u + (q & 63u);
 }
 
-__device__ __forceinline__ WaveGeom wave_geom(int W, int H, int bx, const uint32_t *__restrict__ bin_offset,
+__device__ __forceinline__ WaveGeom wave_geom(int W, int H, int bx, const GsrBins &bins,
                                               const uint32_t *__restrict__ wg_order, uint32_t list_pos) {
     WaveGeom g;
     const int tid = threadIdx.x;
@@ -43,9 +43,24 @@ __device__ __forceinline__ WaveGeom wave_geom(int W, int H, int bx, const uint32
     g.px = bx_i * GSR_BIN + (g.lane & 7);
     g.py = by_i * GSR_BIN + (g.lane >> 3);
     g.inside = g.px < W && g.py < H;
-    g.r0 = bin_offset[g.bin];
-    g.r1 = bin_offset[g.bin + 1];
+    gsr_bin_range(bins, (uint32_t)g.bin, g.r0, g.r1);
     return g;
+}
+
+// Training workspaces: "no gradient record yet" for every slot of the view, written by the FORWARD compositing launch -- every workgroup clears its
+// share of the flag bytes [0, num_slots) with 16-byte stores (one per lane at config 2: 2.3 MB over 16,384 workgroups).  Until round 6 k_scatter cleared
+// the slots of its own Gaussians; direct lists have no scatter pass, and the slot total is only known once the scan has run.  The section is 256-byte
+// aligned and padded, so whole 16-byte words up to the rounded-up slot count stay inside it (num_slots <= capacity, or the view overflowed and
+// nothing runs).
+__device__ __forceinline__ void clear_record_flags(uint8_t *__restrict__ inst_valid, const GsrHeader *__restrict__ hdr, int tid, int nthreads) {
+    if (!inst_valid) return;
+    const uint32_t n16 = (hdr->num_slots + 15u) >> 4;
+    const uint32_t per = (n16 + gridDim.x - 1u) / gridDim.x;
+    const uint32_t w0 = blockIdx.x * per;
+    for (uint32_t k = (uint32_t)tid; k < per; k += (uint32_t)nthreads) {
+        const uint32_t w = w0 + k;
+        if (w < n16) reinterpret_cast<uint4 *>(inst_valid)[w] = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 
 // overflowed forward: this wave's pixels become a defined blank (zero colour, T = 1, no contributor)

@@ -113,18 +113,20 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
 #endif
 template <bool KEEP>
 __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
-                                                            const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                            GsrBins bins, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             float *__restrict__ out_color, float *__restrict__ final_T,
-                                                            uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr, int wave_prio) {
+                                                            uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr, uint8_t *__restrict__ inst_valid,
+                                                            int wave_prio) {
     __shared__ float4 sCol[WAVE];  // {opacity, r, g, b} of the 64 staged splats
     const WgTrace trace(blockIdx.x);
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
-    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    const WaveGeom g = wave_geom(W, H, bx, bins, wg_order, list_pos);
     if (hdr->overflow) {  // nothing can be rendered from truncated lists: a deterministic zero image instead of uninitialised memory
         fwd_write_blank(g, W, H, out_color, final_T, n_contrib);
         return;
     }
+    if (KEEP) clear_record_flags(inst_valid, hdr, g.lane, WAVE);
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);
     const int lane = g.lane;
     const float cx = (float)(g.px - (lane & 7)) + 3.5f, cy = (float)(g.py - (lane >> 3)) + 3.5f;  // bin centre
@@ -313,7 +315,7 @@ __device__ __forceinline__ void tiles_bwd_group(TileBwdState &st, const f32x16 &
 #endif
 template <bool CG>
 __global__ __launch_bounds__(64, CG ? 2 : GSR_BWD_NOCOLOR_WAVES) void k_composite_bwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
-                                                            const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
+                                                            GsrBins bins, const uint32_t *__restrict__ wg_order,
                                                             const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
                                                             const float *__restrict__ dL_dpix, const float *__restrict__ final_T,
                                                             const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ goff,
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(64, CG ? 2 : GSR_BWD_NOCOLOR_WAVES) void k_composit
     const WgTrace trace(gridDim.x + blockIdx.x);
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
     if (list_pos >= hdr->num_busy_wgs) return;  // idle workgroups sit at the end of wg_order
-    const WaveGeom g = wave_geom(W, H, bx, bin_offset, wg_order, list_pos);
+    const WaveGeom g = wave_geom(W, H, bx, bins, wg_order, list_pos);
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);
     if (r1 <= r0) return;
     const int lane = g.lane;
@@ -516,20 +518,20 @@ __global__ __launch_bounds__(64) void k_selftest_tiles(float *__restrict__ out) 
 
 }  // namespace
 
-void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
-                                    const GsrHeader *hdr, bool keep_state, bool wave_prio, hipStream_t s) {
+                                    const GsrHeader *hdr, uint8_t *inst_valid, bool keep_state, bool wave_prio, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
     if (keep_state)
-        hipLaunchKernelGGL(k_composite_fwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list,
-                           bg, out_color, final_T, n_contrib, hdr, wave_prio ? 1 : 0);
+        hipLaunchKernelGGL(k_composite_fwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list,
+                           bg, out_color, final_T, n_contrib, hdr, inst_valid, wave_prio ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_composite_fwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list,
-                           bg, out_color, final_T, n_contrib, hdr, wave_prio ? 1 : 0);
+        hipLaunchKernelGGL(k_composite_fwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list,
+                           bg, out_color, final_T, n_contrib, hdr, nullptr, wave_prio ? 1 : 0);
 }
 
-void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, const uint32_t *bin_offset, const uint32_t *wg_order,
+void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T,
                                     const uint32_t *n_contrib, const uint32_t *goff, const uint32_t *gpart, uint8_t *inst_valid, float *inst_dop,
                                     GsrGradAcc *inst_grad, const GsrHeader *hdr, bool color_grad, bool wave_prio, hipStream_t s) {
@@ -556,10 +558,10 @@ void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat
     }
     const uint32_t prio_from_wg = wave_prio ? res : 0u;
     if (color_grad)
-        hipLaunchKernelGGL(k_composite_bwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
+        hipLaunchKernelGGL(k_composite_bwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list, bg,
                            dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr, prio_from_wg);
     else
-        hipLaunchKernelGGL(k_composite_bwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bin_offset, wg_order, point_list, bg,
+        hipLaunchKernelGGL(k_composite_bwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list, bg,
                            dL_dpix, final_T, n_contrib, goff, gpart, inst_valid, inst_dop, inst_grad, hdr, prio_from_wg);
 }
 

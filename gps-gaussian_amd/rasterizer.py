@@ -85,6 +85,27 @@ def _capacity_for(st, P):
     return int(min(max(st["floor"], int(P * st["ratio"] * 2.0) + 4096), 0x7fffffff))
 
 
+_DIRECT_CAP = 1024  # entries per bin of direct lists (GSR_DIRECT_MAX_CAP: one wave sorts a bin's list)
+
+
+def _bin_capacity(st, W, H):
+    """Per-bin capacity of DIRECT bin lists for the next view on this device, or 0 = scanned lists (include/gpsgs.h GsrViewExt.bin_capacity).
+    Direct lists drop two dependent launches from the forward (scan -> scatter) but a bin holds at most `capacity` entries: they are used until
+    this device sees bin lists longer than 768 entries (`big_bins`, _note_longest -- the untrained-heads regime, lists of 1,000-3,000), and for images
+    of up to 65,536 bins (2048^2).  A view that turns out to need longer lists is reported like an overflow and repaired by the callers' re-run
+    loops with scanned lists.  GPSGS_LISTS=scanned / direct forces the form (direct: still subject to the size limits)."""
+    m = os.environ.get("GPSGS_LISTS", "auto")
+    if m not in ("auto", "scanned", "direct"):
+        raise ValueError("GPSGS_LISTS must be 'auto', 'scanned' or 'direct'")
+    if m == "scanned" or (m == "auto" and st.get("big_bins", False)):
+        return 0
+    key = ("direct_ok", W, H)
+    ok = st.get(key)
+    if ok is None:
+        ok = st[key] = bool(_capi.lib().gsr_direct_lists_ok(W, H, _DIRECT_CAP))
+    return _DIRECT_CAP if ok else 0
+
+
 def _composite_flag():
     """GPSGS_COMPOSITE=valu: the compositing kernels that evaluate every (pixel, splat) exponent on the vector ALUs (gsr_composite.hip).
     GPSGS_COMPOSITE=tiles: the kernels that take the exponents from bf16 matrix-core tiles (gsr_composite_tiles.hip; exact split
@@ -155,8 +176,7 @@ def _drain_pending(st, block=False):
                 npts, longest = int(w32[6]), int(w32[3])
                 _rings[(dev_index, "notify")].release(slot)
                 _learn(st, R, need, P if P is not None else npts, longest)
-                if longest > 768:
-                    st["big_bins"] = True
+                _note_longest(st, longest)
             else:
                 _, ev, hdr, P = ent
                 if block:
@@ -194,6 +214,21 @@ def _learn(st, R, need, P, longest=None):
         st["floor"] = max(st["floor"], min(int(need * 1.25) + 4096, 0x7fffffff))
         if longest is not None:
             st["longest"] = longest  # the next view's work-order hint (GsrViewExt.order_hint): longest bin list of this one
+
+
+def _note_longest(st, longest):
+    """`big_bins` -- this device renders views with long bin lists (the untrained-heads regime): the large-list sort launches are issued and the lists are
+    SCANNED, not direct.  Set by one list beyond 768 entries (three quarters of what one sorting wave / one direct bin holds); cleared again after eight
+    views in a row whose longest list stayed below 512 (stage-2 training leaves the regime as the scales shrink: the fast path must come back)."""
+    with _lock:
+        if longest > 768:
+            st["big_bins"], st["short_streak"] = True, 0
+        elif longest <= 512 and st.get("big_bins", False):
+            st["short_streak"] = st.get("short_streak", 0) + 1
+            if st["short_streak"] >= 8:
+                st["big_bins"], st["short_streak"] = False, 0
+        else:
+            st["short_streak"] = 0
 
 
 def _ptr(t):
@@ -378,12 +413,13 @@ class _Rows:
         self.ptr = offsets.data_ptr() + 4 * self.index
 
 
-def _ext(rows, hint, appear=None):
+def _ext(rows, hint, appear=None, bin_cap=0):
     """appear: None, or (shs, sh_degree, campos, cov3D_precomp, dL_dsh, dL_dcov3D) tensors / None -- the SH-colour and precomputed-covariance
     inputs (and, for the backward, their gradient arrays)."""
     e = _capi.GsrViewExt()
     e.row_range = rows.ptr if rows is not None else None
     e.order_hint = int(hint) & 0xffffffff
+    e.bin_capacity = int(bin_cap)
     if appear is not None:
         shs, deg, campos, cov, d_sh, d_cov = appear
         if shs is not None:
@@ -469,15 +505,19 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             if radii is None or radii.dtype is not torch.int32 or radii.device != dev or radii.numel() != N or not radii.is_contiguous():
                 raise RuntimeError("gps_gaussian_amd: a row-range view needs radii_out: contiguous int32 [rows of the arrays] on the inputs' device")
         # inference (no input needs a gradient): skip the backward tail of the workspace (37 B per instance slot)
-        ws_bytes = lib.gsr_workspace_bytes if needs_grad else lib.gsr_workspace_bytes_forward_only
+        fwd_only = 0 if needs_grad else 1
         # a row-range view's P is only a bound: the instance capacity follows the Gaussian counts seen so far on this device
         p_est = P if rows is None else min(P, int(st.get("last_points", P) * 1.25) + 4096)
         early = mode in ("sync", "deferred") and P > 0 and _early_notify
         ring = _ring(dev) if early else None
 
+        scanned_only = [False]
+
         def launch(cap):
-            """Enqueue the whole forward against an instance capacity.  -> (workspace, bytes, notify slot or None)"""
-            nbytes = ws_bytes(P, W, H, cap)
+            """Enqueue the whole forward against an instance capacity.  -> (workspace, bytes, notify slot or None, per-bin capacity of its lists)"""
+            # direct lists unless this device sees long bin lists -- or THIS view has just shown one (a repair run; also under GPSGS_LISTS=direct)
+            bin_cap = 0 if scanned_only[0] else _bin_capacity(st, W, H)
+            nbytes = lib.gsr_workspace_bytes_ex(P, W, H, cap, bin_cap, fwd_only)
             st["last_ws_bytes"] = nbytes  # reported by last_stats(): what one view in flight holds (forward-only workspaces are ~3x smaller)
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             flags, note = base_flags, None
@@ -493,16 +533,16 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
                 #  launches the large-list sorts -- they return at once when the view's longest list is short: ADVICE r04)
                 if mode == "sync" and not st.get("big_bins", False):
                     flags |= _capi.GSR_FLAG_NO_LARGE_SORT
-            ext = _ext(rows, st.get("longest", 0), appear)  # work order: longest lists first, relative to the longest list seen on this device
+            ext = _ext(rows, st.get("longest", 0), appear, bin_cap)  # work order: longest lists first, relative to the longest list seen on this device
             rc = lib.gsr_forward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier), float(rs.tanfovx),
                                     float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(color), _ptr(radii), _ptr(ws), nbytes, cap, flags,
                                     stream, hdr_ptr, seq, C.byref(ext))
             if rc != 0 and note is not None:
                 ring.release(note[0])
             _capi.check(rc, "gsr_forward_ex")
-            return ws, nbytes, note
+            return ws, nbytes, note, bin_cap
 
-        def settle(note, cap):
+        def settle(note, cap, bin_cap):
             """Wait for a notification and learn from it.  -> (overflowed, R)"""
             slot, hdr, w32, seq = note
             try:
@@ -512,11 +552,12 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             finally:
                 ring.release(slot)  # the host has seen the sequence word (or gave up): the slot may be reissued
             _learn(st, R, need, npts if rows is not None else P, longest)
-            if longest > 768:
-                st["big_bins"] = True  # sticky, with margin: from now on the large-list sort is always launched
+            _note_longest(st, longest)  # with margin: from now on the large-list sorts are launched and the lists are scanned
             if overflow and rows is not None and npts > P:
                 raise RuntimeError("gps_gaussian_amd: the row range holds %d Gaussians, more than the capacity of %d rows the view was sized for" % (npts, P))
-            if overflow and cap >= 0x7fffffff:
+            if overflow and bin_cap and longest > bin_cap:
+                scanned_only[0] = True  # a list that does not fit a direct bin: the repair run uses scanned lists (and _note_longest has set big_bins)
+            elif overflow and cap >= 0x7fffffff:
                 raise _too_many(R)
             return bool(overflow), R
 
@@ -530,18 +571,18 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
                       view=view.cpu().numpy(), proj=proj.cpu().numpy(), bg=bg.cpu().numpy(), W=W, H=H,
                       tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy), scale_modifier=float(rs.scale_modifier), cap=cap, needs_grad=bool(needs_grad))
         while True:
-            ws, nbytes, note = launch(cap)
+            ws, nbytes, note, bin_cap = launch(cap)
             if note is not None:
                 if _deferred_list() is not None:
                     # checked when the enclosing defer_capacity_checks() exits (several views in flight); an overflow is repaired there, in
                     # place: same output tensors, a larger workspace in ctx.ws_box
-                    box = [ws, cap]
+                    box = [ws, cap, bin_cap]
 
                     def finish(note=note):
                         with torch.cuda.stream(cur_stream):
-                            while settle(note, box[1])[0]:
+                            while settle(note, box[1], box[2])[0]:
                                 box[1] = _capacity_for(st, p_est)  # the in-flight kernels of the failed attempt exit at once on the overflow flag
-                                box[0], _, note = launch(box[1])
+                                box[0], _, note, box[2] = launch(box[1])
 
                     _deferred_list().append(finish)
                     break
@@ -550,7 +591,7 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
                     with _lock:
                         st["pending"].append(("note", note, cur_stream, P if rows is None else None, dev.index))
                     break
-                if not settle(note, cap)[0]:
+                if not settle(note, cap, bin_cap)[0]:
                     break
                 cap = _capacity_for(st, p_est)  # grown by _learn; the in-flight kernels of the failed attempt exit at once on the overflow flag
                 continue
@@ -569,9 +610,14 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             ev.synchronize()
             R, overflow, need = _decode(hdr)
             npts = int(hdr[3]) & 0xffffffff
-            _learn(st, R, need, npts if rows is not None else P, (int(hdr[1]) >> 32) & 0xffffffff)
+            longest = (int(hdr[1]) >> 32) & 0xffffffff
+            _learn(st, R, need, npts if rows is not None else P, longest)
+            _note_longest(st, longest)
             if not overflow:
                 break
+            if bin_cap and longest > bin_cap:
+                scanned_only[0] = True
+                continue  # re-run with scanned lists
             if rows is not None and npts > P:
                 raise RuntimeError("gps_gaussian_amd: the row range holds %d Gaussians, more than the capacity of %d rows the view was sized for" % (npts, P))
             if cap >= 0x7fffffff:
@@ -579,6 +625,7 @@ def _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, ra
             cap = _capacity_for(st, p_est)  # grown by _learn; re-run the whole (cheap) forward
     ctx.raster_settings = rs
     ctx.cap = cap
+    ctx.bin_cap = bin_cap
     ctx.family = family  # the backward must repeat the forward's per-pixel decisions: same kernel family
     ctx.extra_flags = extra
     ctx.rows = rows
@@ -601,8 +648,9 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
     cap = ctx.cap
     rows = getattr(ctx, "rows", None)
     box = getattr(ctx, "ws_box", None)
+    bin_cap = getattr(ctx, "bin_cap", 0)
     if box is not None:  # forward ran inside defer_capacity_checks(): the workspace may have been replaced by the overflow repair
-        ws, cap = box
+        ws, cap, bin_cap = box
     dev = m3.device
     N = m3.shape[0]
     P = N if rows is None else rows.capacity
@@ -632,7 +680,7 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
         d_sh = torch.empty_like(sh) if sh is not None else None
         d_cov = torch.empty_like(cov) if cov is not None else None
         if P > 0:
-            ext = _ext(rows, 0, (sh, int(rs.sh_degree), campos, cov, d_sh, d_cov) if (sh is not None or cov is not None) else None)
+            ext = _ext(rows, 0, (sh, int(rs.sh_degree), campos, cov, d_sh, d_cov) if (sh is not None or cov is not None) else None, bin_cap)
             rc = lib.gsr_backward_ex(P, W, H, _ptr(m3), _ptr(col), _ptr(opa), _ptr(sca), _ptr(rot), float(rs.scale_modifier),
                                      float(rs.tanfovx), float(rs.tanfovy), _ptr(view), _ptr(proj), _ptr(bg), _ptr(radii), _ptr(g),
                                      _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_rot), _ptr(ws),
@@ -725,9 +773,11 @@ def last_stats(device=None):
     return dict(_dev_state(dev), pending=len(_dev_state(dev)["pending"]))
 
 
-def export_state(ws, P, W, H, cap):
+def export_state(ws, P, W, H, cap, bin_cap=0):
     """Debug/parity helper: unpack a forward's workspace into tensors: depth, xy, conic_opacity, rect (the 8x8-BIN rect
-    bx0,by0,bx1,by1 each Gaussian is listed in), ranges [bx*by, 2] (per-bin list range), point_list, final_T, n_contrib."""
+    bx0,by0,bx1,by1 each Gaussian is listed in), ranges [bx*by, 2] (per-bin list range), point_list, final_T, n_contrib.
+    bin_cap: the per-bin capacity the forward used (ctx.bin_cap; 0 = scanned lists) -- with direct lists point_list holds every bin's segment
+    (bins x bin_cap entries, indexed by `ranges`)."""
     lib = _capi.lib()
     dev = ws.device
     hdr = ws[:16].view(torch.int64).cpu()
@@ -736,15 +786,16 @@ def export_state(ws, P, W, H, cap):
     out = dict(
         depth=torch.empty(P, device=dev), xy=torch.empty(P, 2, device=dev), conic_opacity=torch.empty(P, 4, device=dev),
         rect=torch.empty(P, 4, dtype=torch.int32, device=dev), ranges=torch.empty(bx * by, 2, dtype=torch.int64, device=dev),
-        point_list=torch.empty(max(cap, 1), dtype=torch.int32, device=dev), final_T=torch.empty(H, W, device=dev),
+        point_list=torch.empty(max(bx * by * bin_cap if bin_cap else cap, 1), dtype=torch.int32, device=dev), final_T=torch.empty(H, W, device=dev),
         n_contrib=torch.empty(H, W, dtype=torch.int32, device=dev))
     with torch.cuda.device(dev):
-        rc = lib.gsr_export_state(_ptr(ws), P, W, H, cap, _ptr(out["depth"]), _ptr(out["xy"]), _ptr(out["conic_opacity"]),
+        rc = lib.gsr_export_state(_ptr(ws), P, W, H, cap, int(bin_cap), _ptr(out["depth"]), _ptr(out["xy"]), _ptr(out["conic_opacity"]),
                                   _ptr(out["rect"]), _ptr(out["ranges"]), _ptr(out["point_list"]), _ptr(out["final_T"]),
                                   _ptr(out["n_contrib"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _capi.check(rc, "gsr_export_state")
     torch.cuda.synchronize(dev)
-    out["point_list"] = out["point_list"][:R]
+    if not bin_cap:
+        out["point_list"] = out["point_list"][:R]
     out["num_rendered"] = R
     out["bx"], out["by"] = bx, by
     out["overflow"] = int(hdr[1]) & 0xffffffff

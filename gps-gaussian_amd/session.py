@@ -46,19 +46,21 @@ class RasterSession:
                 o = (o + 3) // 4 * 4  # 16-byte alignment (the quaternion gradient is stored as float4)
                 self.grads[name] = self._gbuf[o:o + self.P * c].view(self.P, c)
                 o += P_ * c
-        self._ws_bytes = self.lib.gsr_workspace_bytes if self.training else self.lib.gsr_workspace_bytes_forward_only
+        self.bin_cap = 0  # per-bin capacity of the current workspace's lists (0 = scanned lists; rasterizer._bin_capacity)
+        self._scanned_only = False  # the current view has shown a list too long for direct bins: its repair run uses scanned lists
 
-    def _ensure_ws(self, cap, stream):
+    def _ensure_ws(self, cap, stream, bin_cap=0):
         """The workspace for `cap` instances, allocated on `stream` -- the stream its kernels are launched on.  (allocated under PyTorch's
         ambient current stream, the block belonged to THAT stream's pool while its kernels ran on `stream`; on replacement it went straight back to the
         pool and a later ambient-stream allocation could reuse it under the in-flight forward / backward.)  A replaced workspace is handed back with
         record_stream() for every stream the session ever launched on it, so the allocator waits for those kernels before reusing the block."""
-        if self.ws is None or cap != self.cap:
+        if self.ws is None or cap != self.cap or bin_cap != self.bin_cap:
             old = self.ws
             if old is not None:
                 for st in self._ws_streams:
                     old.record_stream(st)
-            self.nbytes = self._ws_bytes(self.P, self.W, self.H, cap)
+            self.nbytes = self.lib.gsr_workspace_bytes_ex(self.P, self.W, self.H, cap, bin_cap, 0 if self.training else 1)
+            self.bin_cap = bin_cap
             with torch.cuda.stream(stream):
                 self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=self.dev)
             self._ws_streams = [stream]
@@ -96,6 +98,7 @@ class RasterSession:
         self._in = (ptrs, fl, cam, family, (means3D, colors, opacities, scales, rotations, viewmatrix, projmatrix, bg))  # keeps the inputs alive
         st = RZ._dev_state(self.dev)
         self._cur = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        self._scanned_only = False
         self._enqueue(max(self.cap, RZ._capacity_for(st, P)))
 
     def _enqueue(self, cap):
@@ -104,7 +107,7 @@ class RasterSession:
         st = RZ._dev_state(self.dev)
         stream = self._cur.cuda_stream
         flags = RZ._extra_flags | family
-        self._ensure_ws(cap, self._cur)
+        self._ensure_ws(cap, self._cur, 0 if (P == 0 or self._scanned_only) else RZ._bin_capacity(st, W, H))
         if P == 0:
             _capi.check(lib.gsr_forward(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
                                         self.nbytes, cap, flags, stream), "gsr_forward")
@@ -114,7 +117,7 @@ class RasterSession:
         slot, hdr, w32, hdr_ptr, seq = ring.acquire_notify()
         skip_large = not st.get("big_bins", False)
         f = (flags & ~_capi.GSR_FLAG_NO_LARGE_SORT) | (_capi.GSR_FLAG_NO_LARGE_SORT if skip_large else 0)
-        ext = RZ._ext(None, st.get("longest", 0))  # work order: longest lists first, relative to the longest list seen on this device
+        ext = RZ._ext(None, st.get("longest", 0), None, self.bin_cap)  # work order: longest lists first, relative to the longest list seen on this device
         rc = lib.gsr_forward_ex(P, W, H, *ptrs, *fl, *cam, self.color.data_ptr(), self.radii.data_ptr(), self.ws.data_ptr(),
                                 self.nbytes, cap, f, stream, hdr_ptr, seq, C.byref(ext))
         if rc != 0:
@@ -135,12 +138,13 @@ class RasterSession:
             finally:
                 RZ._ring(self.dev).release(slot)
             RZ._learn(st, R, need, self.P, longest)
-            if longest > 768:
-                st["big_bins"] = True
+            RZ._note_longest(st, longest)
             if not overflow:
                 self._pending = None
                 break
-            if self.cap >= 0x7fffffff:
+            if self.bin_cap and longest > self.bin_cap:
+                self._scanned_only = True  # a list that does not fit a direct bin: the re-run below uses scanned lists
+            elif self.cap >= 0x7fffffff:
                 raise RuntimeError("gps_gaussian_amd: this view needs %d (Gaussian, bin) instances, more than the 2^31 - 1 the workspace layout can address" % R)
             self._enqueue(RZ._capacity_for(st, self.P))  # a larger workspace (allocated on the view's own stream); the in-flight kernels of the failed attempt exit at once on the overflow flag
         return self.color, self.radii
@@ -159,10 +163,11 @@ class RasterSession:
         if not any(st is bstream or st == bstream for st in self._ws_streams):
             self._ws_streams.append(bstream)  # (the caller orders this stream against the forward's; the workspace must outlive both)
         if self.P > 0:
-            rc = self.lib.gsr_backward(self.P, self.W, self.H, *ptrs, *fl, *cam, self.radii.data_ptr(), g, G["means3D"].data_ptr(),
-                                       G["means2D"].data_ptr(), G["colors"].data_ptr(), G["opacities"].data_ptr(), G["scales"].data_ptr(),
-                                       G["rotations"].data_ptr(), self.ws.data_ptr(), self.nbytes, self.cap,
-                                       RZ._extra_flags | family | (0 if color_grad else _capi.GSR_FLAG_NO_COLOR_GRAD),
-                                       bstream.cuda_stream)
-            _capi.check(rc, "gsr_backward")
+            ext = RZ._ext(None, 0, None, self.bin_cap)
+            rc = self.lib.gsr_backward_ex(self.P, self.W, self.H, *ptrs, *fl, *cam, self.radii.data_ptr(), g, G["means3D"].data_ptr(),
+                                          G["means2D"].data_ptr(), G["colors"].data_ptr(), G["opacities"].data_ptr(), G["scales"].data_ptr(),
+                                          G["rotations"].data_ptr(), self.ws.data_ptr(), self.nbytes, self.cap,
+                                          RZ._extra_flags | family | (0 if color_grad else _capi.GSR_FLAG_NO_COLOR_GRAD),
+                                          bstream.cuda_stream, C.byref(ext))
+            _capi.check(rc, "gsr_backward_ex")
         return G

@@ -43,7 +43,9 @@ extern "C" {
 #define GPSGS_ABI_VERSION 4 /* 2: + GsrViewExt, gsr_forward_ex, gsr_backward_ex; header words num_points / row_overflow (additive)
                                3: GsrViewExt grew from 32 to 80 bytes: SH colours and precomputed 3D covariances (the `shs` / `cov3D_precomp`
                                   inputs of the upstream module, + their gradients); zero-initialised it means what version 2 meant
-                               4: + gsr_mark_visible (upstream GaussianRasterizer.markVisible); gsr_debug_count_records takes workspace_bytes */
+                               4: + gsr_mark_visible (upstream GaussianRasterizer.markVisible); gsr_debug_count_records takes workspace_bytes;
+                                  DIRECT bin lists: GsrViewExt.reserved0 became bin_capacity (0 = what version 3 did), gsr_workspace_bytes_ex,
+                                  gsr_direct_lists_ok; gsr_export_state / gsr_debug_count_records take bin_capacity */
 
 enum {
     GPSGS_OK = 0,
@@ -116,6 +118,11 @@ typedef struct GsrHeader {      /* first bytes of the workspace, device memory *
     uint32_t reserved[8];
 } GsrHeader;
 
+/* direct lists (GsrViewExt.bin_capacity): 1 if this image size and capacity can use them (capacity a multiple of 64 in 64..1024, at most 65,536 bins) */
+int gsr_direct_lists_ok(int width, int height, uint32_t bin_capacity);
+/* workspace size for either list form (bin_capacity 0 = scanned: then equal to the two functions below); 0 on invalid arguments.  With direct lists
+ * instance_capacity still bounds the gradient-record slots of a training workspace (header.num_slots); the lists themselves take bins x bin_capacity entries */
+size_t gsr_workspace_bytes_ex(int P, int width, int height, int64_t instance_capacity, uint32_t bin_capacity, int forward_only);
 size_t gsr_workspace_bytes(int P, int width, int height, int64_t instance_capacity);              /* forward + backward */
 size_t gsr_workspace_bytes_forward_only(int P, int width, int height, int64_t instance_capacity); /* inference: no backward tail; a forward on
                                                                                                      such a workspace also skips the per-pixel state
@@ -132,7 +139,7 @@ int gsr_forward(int P, int width, int height, const float *means3D, const float 
 /* gsr_forward with EARLY capacity notification.  `host_header_out` is 32 bytes of PINNED host memory the device can write
  * (hipHostMalloc / hipHostRegister; torch pin_memory()).  As soon as the binning scan knows the instance count -- about a fifth
  * of the way into the forward, before scatter / sort / compositing run -- the device stores the first 28 header bytes
- * {u64 num_rendered; u32 overflow, max_tile_count, num_busy_wgs, num_slots, 0} there and then release-stores `notify_seq`
+ * {u64 num_rendered; u32 overflow, max_tile_count, num_busy_wgs (0 with direct lists: the work order is made later), num_slots, 0} there and then release-stores `notify_seq`
  * (non-zero, chosen by the caller, different from the word's current value) into the u32 at byte 28.  The host spins on that
  * word instead of waiting for the whole forward: the capacity check of the reference's blocking `num_rendered` readback
  * (rasterizer_impl.cu forward, cudaMemcpy of the scan total) then costs no GPU idle time.  With P == 0 nothing is written.
@@ -169,7 +176,13 @@ typedef struct GsrViewExt {
      *                  untouched (they may be NULL). */
     uint32_t sh_degree;
     uint32_t sh_coeffs;
-    uint32_t reserved0;
+    /* ---- ABI 4: DIRECT bin lists.  0 = scanned lists (every earlier version).  > 0 (a multiple of 64, <= 1024; gsr_direct_lists_ok()): every 8x8-pixel bin
+     *   owns a fixed-capacity segment of bin_capacity list entries, so an instance's slot is known when the count atomic of the preprocess returns: the
+     *   scatter pass runs inside the preprocess, and the scan (header, work order) rides in the sort launch -- three dependent launches in front of the
+     *   compositing instead of five.  The workspace must be sized with gsr_workspace_bytes_ex(..., bin_capacity, ...); forward and backward of a view must
+     *   pass the same value.  A view whose longest list exceeds bin_capacity is NOT rendered: header.overflow = 1 with header.max_tile_count >
+     *   bin_capacity -- repeat it with a larger capacity or with scanned lists (the capacity question upstream answers with a blocking read of R). */
+    uint32_t bin_capacity;
     const float *shs;
     const float *campos;
     const float *cov3D_precomp;
@@ -225,8 +238,8 @@ int gsr_selftest(float *out4_device, void *stream);
 
 /* Diagnostic: after a gsr_backward on a training workspace, out2_device[0] = gradient-record slots that hold a record (one per (Gaussian, bin) instance
  * that received gradient), out2_device[1] = slots of the view (header.num_slots).  Enqueues a 16-byte memset + one kernel; does not synchronise. */
-int gsr_debug_count_records(const void *workspace, size_t workspace_bytes, int P, int width, int height, int64_t instance_capacity, unsigned long long *out2_device,
-                            void *stream); /* GPSGS_E_WORKSPACE for a forward-only workspace (it has no record slots) */
+int gsr_debug_count_records(const void *workspace, size_t workspace_bytes, int P, int width, int height, int64_t instance_capacity, uint32_t bin_capacity,
+                            unsigned long long *out2_device, void *stream); /* GPSGS_E_WORKSPACE for a forward-only workspace (it has no record slots) */
 
 /* Profiling helper (not thread safe, not for use under graph capture): synchronises, then adds up the hipEvent
  * durations recorded by calls that carried GSR_FLAG_TIMING since the last read.  ms_sum[GSR_STAGE_COUNT] receives the
@@ -236,9 +249,9 @@ int gsr_timing_read(float *ms_sum_host, int *launches_host);
 /* Debug/parity helper: copies selected intermediate arrays out of the workspace into caller DEVICE buffers (any may
  * be NULL): depth[P], xy[P,2], conic_opacity[P,4], rect[P,4] (int32 bx0,by0,bx1,by1: the 8x8-pixel BIN rect the Gaussian
  * is listed in), tile_ranges[NB,2] (int64 list range per bin; NB = (ceil(W/8) rounded up to 4) * ceil(H/8)),
- * point_list[num_rendered] (uint32, sorted per bin), final_T[H,W], n_contrib[H,W] (the last two are only produced by a
+ * point_list[instance_capacity, or NB * bin_capacity with direct lists: indexed by tile_ranges] (uint32, sorted per bin), final_T[H,W], n_contrib[H,W] (the last two are only produced by a
  * forward on a workspace with the backward tail). */
-int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, float *depth,
+int gsr_export_state(const void *workspace, int P, int width, int height, int64_t instance_capacity, uint32_t bin_capacity, float *depth,
                      float *xy, float *conic_opacity, int *rect, int64_t *tile_ranges, uint32_t *point_list,
                      float *final_T, uint32_t *n_contrib, void *stream);
 

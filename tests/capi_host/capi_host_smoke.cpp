@@ -174,6 +174,44 @@ int main() {
             for (int k = 0; k < 3 * P; k++)
                 if (a[k] != b[k] || col[k] != hgc[k]) { printf("wave-priority gradients differ at %d\n", k); return 1; }
         }
+        // ABI version 4: DIRECT bin lists (GsrViewExt.bin_capacity): the workspace is sized with gsr_workspace_bytes_ex, forward and backward carry the
+        // same capacity; image, header totals and gradients must equal the scanned-list baseline bit for bit.  A capacity the longest list does not
+        // fit must come back as an overflow whose header says so (max_tile_count > capacity), and nothing is rendered.
+        {
+            GsrViewExt dx = {};
+            dx.bin_capacity = 512;
+            if (!gsr_direct_lists_ok(W, H, 512) || gsr_direct_lists_ok(W, H, 100) || gsr_direct_lists_ok(W, H, 2048)) { printf("gsr_direct_lists_ok\n"); return 1; }
+            const size_t nb3 = gsr_workspace_bytes_ex(P, W, H, cap, 512, 0);
+            if (nb3 == 0 || gsr_workspace_bytes_ex(P, W, H, cap, 0, 0) != nbytes) { printf("gsr_workspace_bytes_ex\n"); return 1; }
+            void *ws3; CK(hipMalloc(&ws3, nb3));
+            rc = gsr_forward_ex(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color2, radii2, ws3, nb3, cap, TF, st, nullptr, 0u, &dx);
+            if (rc == GPSGS_OK) rc = gsr_backward_ex(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, radii2, dgp, w3, w2, wgc, wgo, wgs, wgr, ws3, nb3, cap, TF, st, &dx);
+            if (rc != GPSGS_OK) { printf("direct lists rc=%d\n", rc); return 1; }
+            GsrHeader h3;
+            if (gsr_read_header(ws3, &h3, st) != GPSGS_OK) return 1;
+            if (h3.overflow || h3.num_rendered != h.num_rendered || h3.max_tile_count != h.max_tile_count || h3.num_busy_wgs != h.num_busy_wgs || h3.num_slots != h.num_slots) {
+                printf("direct-list header differs: overflow=%u R=%llu longest=%u busy=%u slots=%u\n", h3.overflow, (unsigned long long)h3.num_rendered, h3.max_tile_count,
+                       h3.num_busy_wgs, h3.num_slots);
+                return 1;
+            }
+            CK(hipMemcpy(img2.data(), color2, img2.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < img.size(); k++) if (img2[k] != img[k]) { printf("direct-list image differs at %zu\n", k); return 1; }
+            std::vector<float> a(3 * P), b(3 * P), col(3 * P);
+            CK(hipMemcpy(a.data(), g3, 12 * P, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), w3, 12 * P, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(col.data(), wgc, 12 * P, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 3 * P; k++)
+                if (a[k] != b[k] || col[k] != hgc[k]) { printf("direct-list gradients differ at %d\n", k); return 1; }
+            if (h.max_tile_count > 64) {  // a capacity of 64 entries per bin cannot hold this view's longest list
+                dx.bin_capacity = 64;
+                const size_t nb4 = gsr_workspace_bytes_ex(P, W, H, cap, 64, 0);
+                if (nb4 == 0 || nb4 > nb3) { printf("workspace for 64-entry bins: %zu\n", nb4); return 1; }
+                rc = gsr_forward_ex(P, W, H, dm, dc, dop, ds, dr, 1.0f, W / (2 * fx), H / (2 * fx), dv, dp, dbg, color2, radii2, ws3, nb4, cap, TF, st, nullptr, 0u, &dx);
+                if (rc != GPSGS_OK || gsr_read_header(ws3, &h3, st) != GPSGS_OK) return 1;
+                if (!h3.overflow || h3.max_tile_count != h.max_tile_count || h3.num_rendered != h.num_rendered) { printf("too long a list for direct bins was not reported\n"); return 1; }
+            }
+            (void)hipFree(ws3);
+        }
         // a range longer than the capacity is reported like an overflow
         std::vector<uint32_t> big = {0u, (uint32_t)(3 * P)};
         uint32_t *dbig = dev(big);

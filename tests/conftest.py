@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _fresh_list_policy(request):
+    """GPU tests: which list form a view gets (direct bin lists / scanned lists) follows what the device has rendered before (rasterizer._note_longest).
+    Every test starts from the same state -- "no long list seen" -- so that its path does not depend on the tests that ran before it."""
+    if request.node.get_closest_marker("gpu") is not None:
+        from gps_gaussian_amd import rasterizer as RZ
+        for st in list(RZ._state.values()):
+            for k in ("big_bins", "short_streak", "longest"):
+                st.pop(k, None)
+    yield
+
+
 def simple_scene(W, H, fx, cx=None, cy=None, bg=(0.0, 0.0, 0.0)):
     """Identity-pose pinhole camera in the layout render() consumes + empty Gaussian lists to fill in."""
     import gps_gaussian_amd  # noqa: F401
@@ -83,7 +95,7 @@ def hip_render(scene, dpix=None, debug=False, shs=None, sh_degree=3, cov3D_preco
     if dpix is not None:
         fn = img.grad_fn  # grab the forward's workspace before backward frees the saved tensors
         ws = [x for x in fn.saved_tensors if x is not None and x.dtype == torch.uint8][0]
-        info = dict(ws=ws, cap=fn.cap)
+        info = dict(ws=ws, cap=fn.cap, bin_cap=getattr(fn, "bin_cap", 0))
         img.backward(torch.from_numpy(np.ascontiguousarray(dpix, dtype=np.float32)).to(dev))
         grads = {k: t[k].grad.cpu().numpy() for k in names}
         grads["means2D"] = m2.grad.cpu().numpy()

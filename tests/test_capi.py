@@ -66,6 +66,21 @@ def test_workspace_bytes_monotone_and_aligned():
     assert lib.gsr_workspace_bytes(-1, 16, 16, 1) == 0
 
 
+def test_workspace_bytes_ex_and_the_limits_of_direct_lists():
+    lib = _capi.lib()
+    for args in ((1000, 256, 256, 10000), (600000, 1024, 1024, 4_000_000), (0, 16, 16, 0)):
+        assert lib.gsr_workspace_bytes_ex(*args, 0, 0) == lib.gsr_workspace_bytes(*args)
+        assert lib.gsr_workspace_bytes_ex(*args, 0, 1) == lib.gsr_workspace_bytes_forward_only(*args)
+    # direct lists: bins x capacity list entries (12 bytes each) instead of instance_capacity of them
+    d = lib.gsr_workspace_bytes_ex(600000, 1024, 1024, 4_000_000, 1024, 0)
+    s_ = lib.gsr_workspace_bytes(600000, 1024, 1024, 4_000_000)
+    assert d % 256 == 0 and 100 << 20 < d - s_ < 200 << 20
+    assert lib.gsr_direct_lists_ok(1024, 1024, 1024) == 1 and lib.gsr_direct_lists_ok(2048, 2048, 512) == 1
+    assert lib.gsr_direct_lists_ok(4096, 2104, 1024) == 0      # more than 65,536 bins
+    assert lib.gsr_direct_lists_ok(1024, 1024, 2048) == 0 and lib.gsr_direct_lists_ok(1024, 1024, 100) == 0 and lib.gsr_direct_lists_ok(1024, 1024, 0) == 0
+    assert lib.gsr_workspace_bytes_ex(1000, 4096, 2104, 10000, 1024, 0) == 0
+
+
 def test_invalid_arguments_are_rejected_without_touching_the_gpu():
     lib = _capi.lib()
     assert lib.gsr_forward(10, 0, 16, *([None] * 5), 1.0, 1.0, 1.0, *([None] * 6), 0, 0, 0, None) == _capi.GPSGS_E_INVALID

@@ -51,12 +51,20 @@ def _hip_kat_render(scene):
         img, radii, _, _ = hip_render(scene)
         return img, radii, None
     img, radii, _, t = hip_render(scene, np.zeros((3, scene["H"], scene["W"]), np.float32))
-    st = RZ.export_state(t["ws"], P, scene["W"], scene["H"], t["cap"])
+    st = RZ.export_state(t["ws"], P, scene["W"], scene["H"], t["cap"], t.get("bin_cap", 0))
     return img, radii, dict(n_contrib=st["n_contrib"].cpu().numpy(), final_T=st["final_T"].cpu().numpy())
 
 
+@pytest.fixture(params=["direct", "scanned"])
+def lists(request, monkeypatch):
+    """Both forms of the per-bin lists (include/gpsgs.h GsrViewExt.bin_capacity): DIRECT -- fixed-capacity segments filled by k_preprocess, scan riding in
+    the sort launch (round 6; what every view with short lists gets) -- and SCANNED -- k_scan_b + k_scatter + k_sort_* (long lists, large images)."""
+    monkeypatch.setenv("GPSGS_LISTS", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("case", kat_cases.ALL, ids=lambda c: c.__name__)
-def test_known_answers_on_gpu(case, family):
+def test_known_answers_on_gpu(case, family, lists):
     case(_hip_kat_render, 2e-6)
 
 
@@ -102,7 +110,7 @@ def _norm_err(a, ref):
 
 
 @pytest.mark.parametrize("name", ["c1_256_30k", "cloud_333x277_20k", "cloud_big_splats_96x80", "hr_512_from_256"])
-def test_forward_backward_parity(name, family):
+def test_forward_backward_parity(name, family, lists):
     import torch
     from gps_gaussian_amd import rasterizer as RZ
     g = _scenes()[name]()
@@ -113,7 +121,7 @@ def test_forward_backward_parity(name, family):
 
     # --- discrete decisions and per-Gaussian geometry: bit-exact (preprocess is compiled without FMA contraction)
     np.testing.assert_array_equal(radii, oradii)
-    st = RZ.export_state(t["ws"], P, W, H, t["cap"])
+    st = RZ.export_state(t["ws"], P, W, H, t["cap"], t.get("bin_cap", 0))
     geom, binning = o.geom(), o.binning()
     vis = oradii > 0
     assert st["overflow"] == 0
@@ -133,7 +141,11 @@ def test_forward_backward_parity(name, family):
     plist = st["point_list"].cpu().numpy().astype(np.int64)
     n_rect = int(((brect[:, 2] - brect[:, 0]) * (brect[:, 3] - brect[:, 1]))[listed].sum())
     assert 0 < st["num_rendered"] <= n_rect            # exact ellipse/bin culling only ever removes instances
-    assert (plist >= 0).all() and (plist < P).all()    # every reserved slot was filled with a real Gaussian id
+    used = np.zeros(plist.shape[0], bool)               # (direct lists: a bin's segment beyond its count is never written)
+    for a_, b_ in ranges:
+        used[a_:b_] = True
+    assert used.sum() == st["num_rendered"]
+    assert (plist[used] >= 0).all() and (plist[used] < P).all()    # every reserved slot was filled with a real Gaussian id
     bxp = st["bx"]
     gx16 = (W + 15) // 16
     depth_bits = geom["depth"].astype(np.float32).view(np.uint32).astype(np.int64)
@@ -238,7 +250,7 @@ def test_every_sort_path(n, expect_path):
     dpix = np.ones((3, 32, 32), np.float32)
     img, radii, grads, t = hip_render(g, dpix)
     o, oimg, oradii = oracle_render(g, "f32")
-    st = RZ.export_state(t["ws"], n, 32, 32, t["cap"])
+    st = RZ.export_state(t["ws"], n, 32, 32, t["cap"], t.get("bin_cap", 0))
     rg = st["ranges"].cpu().numpy()
     lengths = (rg[:, 1] - rg[:, 0]).astype(np.int64)
     longest = int(lengths.max())
@@ -265,6 +277,7 @@ def test_capacity_overflow_is_detected_and_repaired(monkeypatch, early):
     from gps_gaussian_amd import rasterizer as RZ
     from gps_gaussian_amd import synthetic as S
     monkeypatch.setattr(RZ, "_early_notify", early)
+    monkeypatch.setenv("GPSGS_LISTS", "scanned")  # (an inference view with direct lists has no instance capacity to overflow: its twin is test_direct_lists_*)
     g = S.make_uniform_cloud(5000, 128, 96, seed=9, scale_med=0.05)
     o, oimg, _ = oracle_render(g, "f32")
     assert o.num_rendered > 4 * 1024
@@ -313,6 +326,7 @@ def test_deferred_check_mode(monkeypatch):
     from gps_gaussian_amd import synthetic as S
     g = S.make_uniform_cloud(5000, 128, 96, seed=9, scale_med=0.05)
     monkeypatch.setenv("GPSGS_CHECK", "deferred")
+    monkeypatch.setenv("GPSGS_LISTS", "scanned")  # (an inference view with direct lists has no instance capacity to overflow)
     o, oimg, _ = oracle_render(g, "f32")
     img, _, _, _ = hip_render(g)
     solid, _ = touched_by_fragile(o)
@@ -413,7 +427,7 @@ def test_config5_2048_highres_2p4M_gaussians():
     parity_report("config5_2048_2p4M", img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
     assert ((oradii > 0) & ~touched).sum() >= 0.5 * (oradii > 0).sum()
     assert solid.mean() > 0.998 and err[solid].max() <= RGB_TOL and (err > RGB_TOL).sum() <= 400
-    st = RZ.export_state(info["ws"], 2_400_000, 2048, 2048, info["cap"])
+    st = RZ.export_state(info["ws"], 2_400_000, 2048, 2048, info["cap"], info.get("bin_cap", 0))
     assert st["overflow"] == 0 and st["num_rendered"] > 2_400_000
     for k, v in grads.items():
         assert np.isfinite(v).all(), k
@@ -502,7 +516,7 @@ _FUZZ = [  # (W, H, P, seed, scale_med, z_range, behind_frac)
 
 
 @pytest.mark.parametrize("cfg", _FUZZ, ids=lambda c: "%dx%d_P%d" % (c[0], c[1], c[2]))
-def test_fuzz_odd_shapes_and_degenerate_clouds(cfg, family):
+def test_fuzz_odd_shapes_and_degenerate_clouds(cfg, family, lists):
     """Small random clouds on image sizes that are not multiples of the 8-pixel bin or the 16-pixel tile (down to 1x1), with
     Gaussians behind the camera, sub-pixel and screen-filling splats, exactly-zero and exactly-one opacities, duplicated depths:
     radii bit-exact, image and gradients within the north-star tolerances outside fragile pixels."""
@@ -610,10 +624,11 @@ def test_forward_backward_under_hip_graph_capture(monkeypatch):
     torch.cuda.synchronize()
 
 
-def test_skipped_large_sort_launch_is_detected_and_repaired():
+def test_skipped_large_sort_launch_is_detected_and_repaired(monkeypatch):
     """Fresh device state: the first forward leaves out the large-list sort launch.  A bin with more than 1024 entries must then
     come back as a reported overflow and be re-rendered with that launch -- exact result, and the shortcut stays off afterwards."""
     import torch
+    monkeypatch.setenv("GPSGS_LISTS", "scanned")
     from gps_gaussian_amd import rasterizer as RZ
     from gps_gaussian_amd import synthetic as S
 
@@ -688,7 +703,7 @@ def test_unchecked_overflow_gives_a_blank_image_and_zero_gradients(monkeypatch):
     monkeypatch.setattr(RZ, "_capacity_for", lambda st, P: 1024)
     img, radii, grads, info = hip_render(g, dpix)
     torch.cuda.synchronize()
-    st = RZ.export_state(info["ws"], 5000, 128, 96, info["cap"])
+    st = RZ.export_state(info["ws"], 5000, 128, 96, info["cap"], info.get("bin_cap", 0))
     assert st["overflow"] == 1 and st["num_rendered"] > 1024
     assert (img == 0).all()
     for k, v in grads.items():
@@ -880,7 +895,7 @@ def test_exact_bin_culling_is_sound_for_needle_shaped_splats(seed):
     o, _, oradii = oracle_render(g, "f32")
     np.testing.assert_array_equal(radii, oradii)
     geom = o.geom()
-    st = RZ.export_state(info["ws"], P, W, H, info["cap"])
+    st = RZ.export_state(info["ws"], P, W, H, info["cap"], info.get("bin_cap", 0))
     ranges, plist, bxp = st["ranges"].cpu().numpy(), st["point_list"].cpu().numpy().astype(np.int64), st["bx"]
     listed = set()
     for b, (a_, b_) in enumerate(ranges):
@@ -1057,7 +1072,7 @@ def test_row_interval_binning_never_drops_a_pair_the_per_cell_test_lists():
     dpix = np.ones((3, H, W), np.float32)
     img, radii, grads, t = hip_render(g, dpix, debug=True)
     P = g["means3D"].shape[0]
-    st = RZ.export_state(t["ws"], P, W, H, t["cap"])
+    st = RZ.export_state(t["ws"], P, W, H, t["cap"], t.get("bin_cap", 0))
     xy, co, rect = st["xy"].cpu().numpy().astype(np.float64), st["conic_opacity"].cpu().numpy().astype(np.float64), st["rect"].cpu().numpy()
     rg, plist, bx = st["ranges"].cpu().numpy(), st["point_list"].cpu().numpy(), st["bx"]
     listed = set()
@@ -1131,3 +1146,89 @@ def test_full_size_lists_of_thousands_of_keys_are_sorted(scale_modifier, sort_cl
             else:
                 st[k] = v
         torch.cuda.empty_cache()
+
+
+def _stack_scene(n, seed, res=32):
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_uniform_cloud(n, res, res, seed=seed, scale_med=0.2, z_range=(1.0, 6.0), behind_frac=0.0)
+    g["opacities"] = (g["opacities"] * 0.05).astype(np.float32)
+    return g
+
+
+def test_direct_lists_too_long_a_list_is_detected_repaired_with_scanned_lists_and_the_fast_path_comes_back():
+    """Direct bin lists hold 1,024 entries per bin.  Fresh device state: the first view is given direct lists; a bin that needs more must come back
+    as a reported overflow (header: longest list > capacity) and be re-rendered with scanned lists -- exact result.  The device then stays on scanned
+    lists while lists are long, and returns to direct lists after eight views in a row with short ones (rasterizer._note_longest)."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    dev = torch.device("cuda:0")
+    RZ._state.clear()
+    g = _stack_scene(24000, seed=5)   # bins of several thousand entries
+    dpix = np.ones((3, 32, 32), np.float32)
+    img, _, grads, info = hip_render(g, dpix)
+    assert info["bin_cap"] == 0 and RZ._dev_state(dev).get("big_bins") is True
+    o, oimg, _ = oracle_render(g, "f32")
+    solid, touched, bounds = fragile_bounds(o, dpix)
+    assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
+    assert_grad_parity(grads, o.backward(dpix), touched, o.geom()["radii"] > 0, bounds=bounds, strict_min=0.0)  # (a 32 x 32 image: every splat covers it)
+    g2 = _stack_scene(400, seed=6)    # short lists right after: still scanned (hysteresis), still exact
+    o2, oimg2, _ = oracle_render(g2, "f32")
+    solid2, _ = touched_by_fragile(o2)
+    for k in range(9):
+        img2, _, _, info2 = hip_render(g2, dpix)
+        assert np.abs(img2 - oimg2).max(0)[solid2].max() <= RGB_TOL
+        assert info2["bin_cap"] == (0 if k < 8 else RZ._DIRECT_CAP), (k, info2["bin_cap"])
+    assert RZ._dev_state(dev).get("big_bins") is False
+    RZ._state.clear()
+
+
+@pytest.mark.parametrize("scene", ["c1_256_30k", "cloud_big", "empty_borders"])
+def test_direct_and_scanned_lists_give_identical_bits(scene, family, monkeypatch):
+    """The two list forms differ in WHERE a bin's list lives and in which launch produces the work order -- never in what a list holds: after the
+    per-bin sort both are the same ids in the same (depth, id) order, so image, radii, per-pixel state and every gradient must agree bit for bit.
+    debug=True makes the forward validate the direct lists as well (ids of the view, in order)."""
+    from gps_gaussian_amd import rasterizer as RZ, synthetic as S
+    if scene == "c1_256_30k":
+        g = S.make_scene(256, 30000)
+    elif scene == "cloud_big":
+        g = S.make_uniform_cloud(6000, 200, 120, seed=17, scale_med=0.04)
+    else:
+        g = S.make_uniform_cloud(300, 517, 131, seed=18, scale_med=0.01)   # ragged grid edge, most bins empty
+    dpix = np.random.default_rng(4).standard_normal((3, g["H"], g["W"])).astype(np.float32)
+    out = {}
+    for form in ("direct", "scanned"):
+        monkeypatch.setenv("GPSGS_LISTS", form)
+        img, radii, grads, info = hip_render(g, dpix, debug=True)
+        assert (info["bin_cap"] > 0) == (form == "direct")
+        st = RZ.export_state(info["ws"], g["means3D"].shape[0], g["W"], g["H"], info["cap"], info["bin_cap"])
+        rg, pl = st["ranges"].cpu().numpy(), st["point_list"].cpu().numpy()
+        lists_ = [pl[a:b].copy() for a, b in rg]
+        out[form] = (img, radii, grads, st["n_contrib"].cpu().numpy(), st["final_T"].cpu().numpy(), lists_, st["num_rendered"])
+    a, b = out["direct"], out["scanned"]
+    np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+    assert a[6] == b[6] and len(a[5]) == len(b[5]) and all(np.array_equal(x, y) for x, y in zip(a[5], b[5]))
+    for k in a[2]:
+        np.testing.assert_array_equal(a[2][k], b[2][k], err_msg=k)
+
+
+def test_direct_lists_record_slot_overflow_is_repaired(monkeypatch):
+    """With direct lists the instance capacity no longer bounds the lists, but a training workspace still needs one gradient-record slot per bin-rect
+    cell: too small a capacity must be reported (header.num_slots) and repaired like any overflow."""
+    from gps_gaussian_amd import rasterizer as RZ, synthetic as S
+    monkeypatch.setenv("GPSGS_LISTS", "direct")
+    g = S.make_uniform_cloud(5000, 128, 96, seed=9, scale_med=0.05)
+    dpix = np.ones((3, 96, 128), np.float32)
+    _, _, g_ref, _ = hip_render(g, dpix)
+    calls, real = [], RZ._capacity_for
+
+    def tiny_first(st, P):
+        calls.append(1)
+        return 1024 if len(calls) == 1 else real(st, P)
+
+    monkeypatch.setattr(RZ, "_capacity_for", tiny_first)
+    img, _, grads, info = hip_render(g, dpix)
+    assert len(calls) >= 2 and info["bin_cap"] == RZ._DIRECT_CAP
+    for k in grads:
+        np.testing.assert_array_equal(grads[k], g_ref[k], err_msg=k)
+

@@ -86,7 +86,7 @@ def test_splat_centres_exactly_on_pixel_centres(family):
     img, radii, grads, info = hip_render(g, dpix)
     o, oimg, oradii = oracle_render(g, "f32")
     np.testing.assert_array_equal(radii, oradii)
-    st = RZ.export_state(info["ws"], P, W, H, info["cap"])
+    st = RZ.export_state(info["ws"], P, W, H, info["cap"], info.get("bin_cap", 0))
     xy = st["xy"].cpu().numpy()
     vis = oradii > 0
     on_centre = (xy[vis] == np.round(xy[vis])).all(1)

@@ -11,7 +11,7 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 600000
 g = S.make_scene(res, n)
 img, radii, _, info = hip_render(g, np.ones((3, g["H"], g["W"]), np.float32))
-st = RZ.export_state(info["ws"], n, g["W"], g["H"], info["cap"])
+st = RZ.export_state(info["ws"], n, g["W"], g["H"], info["cap"], info.get("bin_cap", 0))
 r = st["ranges"].cpu().numpy()
 cnt = (r[:, 1] - r[:, 0]).astype(np.int64)
 busy = cnt[cnt > 0]
