@@ -690,6 +690,73 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
     return d_m3, d_m2, d_col, d_op, d_sc, d_rot, d_sh, d_cov
 
 
+# ---- the compiled host path (csrc/host_shim.cpp -> lib/_gpsgs_fast.so) -----------------------------------------------------------------------------
+# The call shape the reference uses, in sync mode, goes through a C++ torch::autograd::Function that performs the same steps as _forward_impl /
+# _backward_impl against the same C-ABI; everything else -- and every overflow -- takes the Python path below.  The capacity POLICY stays here.
+_fast = None   # the module, or False when it is switched off / not built
+
+
+def _fast_module():
+    """lib/_gpsgs_fast.so, or False.  GPSGS_FAST=0 switches it off (the Python host path is then used for everything); on a machine where the
+    library was built the module must load -- a missing or stale one is an ImportError, not a silent fallback."""
+    global _fast
+    if os.environ.get("GPSGS_FAST", "1") == "0":
+        return False
+    if _fast is None:
+        if True:
+            import importlib.util
+            path = os.path.join(os.path.dirname(_capi.LIB_PATH), "_gpsgs_fast.so")
+            if not os.path.exists(path):
+                raise ImportError("gps_gaussian_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` (or set GPSGS_FAST=0 "
+                                  "to use the Python host path)." % path)
+            _capi.lib()  # libgpsgs_hip.so first: the extension links against it
+            spec = importlib.util.spec_from_file_location("_gpsgs_fast", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != _capi.lib().gpsgs_abi_version():
+                raise ImportError("gps_gaussian_amd: %s was built against another ABI version" % path)
+            _fast = mod
+    return _fast
+
+
+def _fast_forward(means3D, means2D, opacities, colors_precomp, scales, rotations, rs):
+    """-> (color, radii) through the compiled host path, or None: not its call shape / mode, or the view overflowed (the caller then takes the
+    Python path, which repairs it).  Policy decisions (capacity, list form, flags) are taken here, from the same per-device state."""
+    F = _fast_module()
+    env = os.environ
+    if (not F or rs.debug or _extra_flags or _deferred_list() is not None or env.get("GPSGS_CHECK", "sync") != "sync" or not _early_notify
+            or env.get("GPSGS_DUMP_INPUTS") or not isinstance(means3D, torch.Tensor) or not means3D.is_cuda):
+        return None
+    dev = means3D.device
+    st = _dev_state(dev)
+    if st["pending"]:
+        return None
+    H, W = int(rs.image_height), int(rs.image_width)
+    P = means3D.shape[0]
+    stream = torch._C._cuda_getCurrentRawStream(dev.index)
+    flags = _composite_flag() | _wave_priority_flag(st, stream)
+    if not st.get("big_bins", False):
+        flags |= _capi.GSR_FLAG_NO_LARGE_SORT
+    cap = _capacity_for(st, P)
+    bin_cap = _bin_capacity(st, W, H)
+    out = F.rasterize(means3D, means2D, colors_precomp, opacities, scales, rotations, rs.bg, rs.viewmatrix, rs.projmatrix, H, W, float(rs.tanfovx),
+                      float(rs.tanfovy), float(rs.scale_modifier), cap, bin_cap, st.get("longest", 0), flags)
+    if out is None:
+        return None
+    R, overflow, longest, slots, npts, nbytes = F.last_header()
+    st["last_ws_bytes"] = nbytes
+    _learn(st, R, max(R, slots), P, longest)
+    _note_longest(st, longest)
+    if overflow:
+        return None  # nothing was rendered (the kernels exit on the flag): the Python path re-renders with what was just learnt
+    if _debug_keep_ws:
+        _tls.last_ws = dict(ws=out[2], cap=cap, bin_cap=bin_cap)
+    return out[0], out[1]
+
+
+_debug_keep_ws = False  # tests: both host paths leave {ws, cap, bin_cap} of the last forward in _tls.last_ws (export_state needs them)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, grad_arena=None):
@@ -701,6 +768,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.color_grad = bool(ctx.needs_input_grad[3]) or sh is not None  # (dL/dsh is formed from dL/dcolour)
         color, radii = _forward_impl(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, any(ctx.needs_input_grad),
                                      shs=sh, cov3D_precomp=cov3Ds_precomp)
+        if _debug_keep_ws:
+            _tls.last_ws = dict(ws=ctx.saved[9], cap=ctx.cap, bin_cap=ctx.bin_cap)
         ctx.save_for_backward(*ctx.saved)
         ctx.saved = None
         ctx.mark_non_differentiable(radii)
@@ -739,6 +808,11 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if shs is None and cov3D_precomp is None and grad_arena is None:
+            # the reference's call shape (gaussian_renderer/__init__.py:54-62): the compiled host path, when it applies
+            out = _fast_forward(means3D, means2D, opacities, colors_precomp, scales, rotations, self.raster_settings)
+            if out is not None:
+                return out
         # shs [P, M, 3] are evaluated up to raster_settings.sh_degree towards raster_settings.campos (upstream computeColorFromSH); cov3D_precomp
         # [P, 6] replaces scale + rotation.  The reference passes neither (gaussian_renderer/__init__.py:54-62) but constructs the settings
         # with sh_degree = 3 and campos (:46-47): both inputs are part of the module it imports.

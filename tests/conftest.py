@@ -87,15 +87,18 @@ def hip_render(scene, dpix=None, debug=False, shs=None, sh_degree=3, cov3D_preco
         bg=torch.from_numpy(scene["bg"]).to(dev), scale_modifier=float(scene.get("scale_modifier", 1.0)), viewmatrix=torch.from_numpy(scene["view"]).to(dev),
         projmatrix=torch.from_numpy(scene["proj"]).to(dev), sh_degree=sh_degree, campos=torch.from_numpy(scene["campos"]).to(dev),
         prefiltered=False, debug=debug)
-    img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=t.get("shs"), colors_precomp=t.get("colors"),
-                                           opacities=t["opacities"], scales=t.get("scales"), rotations=t.get("rotations"),
-                                           cov3D_precomp=t.get("cov3D_precomp"))
+    RZ._debug_keep_ws = True  # both host paths (compiled / Python) then leave the forward's workspace for export_state
+    try:
+        img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=t.get("shs"), colors_precomp=t.get("colors"),
+                                               opacities=t["opacities"], scales=t.get("scales"), rotations=t.get("rotations"),
+                                               cov3D_precomp=t.get("cov3D_precomp"))
+    finally:
+        RZ._debug_keep_ws = False
     grads = None
     info = None
+    last = RZ._tls.__dict__.pop("last_ws", None)
     if dpix is not None:
-        fn = img.grad_fn  # grab the forward's workspace before backward frees the saved tensors
-        ws = [x for x in fn.saved_tensors if x is not None and x.dtype == torch.uint8][0]
-        info = dict(ws=ws, cap=fn.cap, bin_cap=getattr(fn, "bin_cap", 0))
+        info = last
         img.backward(torch.from_numpy(np.ascontiguousarray(dpix, dtype=np.float32)).to(dev))
         grads = {k: t[k].grad.cpu().numpy() for k in names}
         grads["means2D"] = m2.grad.cpu().numpy()

@@ -37,6 +37,7 @@ gout = torch.randn(3, rr, rr, device=dev)
 
 def step():
     for v in t.values(): v.grad = None
+    m2.grad = None
     img, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
     if not a.fwd_only:
         img.backward(gout)
