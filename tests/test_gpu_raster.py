@@ -270,6 +270,43 @@ def test_every_sort_path(n, expect_path):
     parity_report("sort_path[%s]" % expect_path, img, oimg, grads, og, solid, touched, visible=oradii > 0, extra=dict(longest_list=longest), bounds=bounds)
 
 
+@pytest.mark.parametrize("levels,n", [(4000, 9000), (4000, 30000), (40, 9000), (40, 30000), (1, 12000)],
+                         ids=["pairs_2k", "pairs_8k", "groups_of_50_2k", "groups_of_200_8k", "one_depth"])
+def test_long_lists_with_equal_depths_come_out_in_index_order(levels, n):
+    """Equal depths must come out in ascending Gaussian index (upstream's stable radix order: depth, then index) from EVERY sort class.  Depths quantised to
+    a few thousand levels give a bin list of ~2,000 - 7,000 keys hundreds of pairs and triples; a few dozen levels give groups of dozens to hundreds of
+    equal depths; one level = every key of a list equal.  (Written for the round-6 experiment that sorted the depth words alone and looked ranks up
+    afterwards -- docs/HISTORY.md; kept because no other test holds the 1,025 - 8,192-key classes to the tie rule.)  Every list of every bin is checked
+    against (depth bits, index) order, and the image against the oracle."""
+    from gps_gaussian_amd import rasterizer as RZ
+    from gps_gaussian_amd import synthetic as S
+    g = S.make_uniform_cloud(n, 32, 32, seed=23, scale_med=0.2, z_range=(1.0, 6.0), behind_frac=0.0)
+    z = g["means3D"][:, 2]
+    zq = (1.0 + np.floor((z - 1.0) / 5.0 * levels) * (5.0 / levels)).astype(np.float32)   # identity pose: view-space depth = z
+    g["means3D"] = np.stack([g["means3D"][:, 0] * zq / z, g["means3D"][:, 1] * zq / z, zq], 1).astype(np.float32)
+    g["opacities"] = (g["opacities"] * 0.05).astype(np.float32)
+    dpix = np.ones((3, 32, 32), np.float32)
+    img, radii, grads, t = hip_render(g, dpix)
+    o, oimg, oradii = oracle_render(g, "f32")
+    np.testing.assert_array_equal(radii, oradii)
+    st = RZ.export_state(t["ws"], n, 32, 32, t["cap"], t.get("bin_cap", 0))
+    rg = st["ranges"].cpu().numpy()
+    lengths = (rg[:, 1] - rg[:, 0]).astype(np.int64)
+    assert ((lengths > 1024) & (lengths <= 8192)).any(), sorted(lengths.tolist())[-5:]
+    depth_bits = o.geom()["depth"].astype(np.float32).view(np.uint32).astype(np.int64)
+    plist = st["point_list"].cpu().numpy().astype(np.int64)
+    ties = 0
+    for a_, b_ in rg:
+        if b_ > a_:
+            ids = plist[a_:b_]
+            assert len(np.unique(ids)) == len(ids)
+            assert (np.diff(depth_bits[ids] * (1 << 32) + ids) > 0).all()
+            ties += int((np.diff(depth_bits[ids]) == 0).sum())
+    assert ties > 100, ties
+    solid, _ = touched_by_fragile(o)
+    assert np.abs(img - oimg).max(0)[solid].max() <= RGB_TOL
+
+
 @pytest.mark.parametrize("early", [True, False], ids=["early-notify", "header-copy"])
 def test_capacity_overflow_is_detected_and_repaired(monkeypatch, early):
     """Both sync-mode checks: the scan kernel's direct store to pinned memory (gsr_forward_notify, default) and the
