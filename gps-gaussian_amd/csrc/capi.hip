@@ -396,6 +396,7 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
     b.shs = shs; b.campos = shs ? ext->campos : nullptr; b.cov3D_precomp = cov3D_precomp;
     b.sh_degree = shs ? ext->sh_degree : 0u; b.sh_coeffs = shs ? ext->sh_coeffs : 0u;
     b.dL_dsh = shs ? ext->dL_dsh : nullptr; b.dL_dcov3D = cov3D_precomp ? ext->dL_dcov3D : nullptr;
+    b.dop_in_record = ((flags & GSR_FLAG_COMPOSITE_TILES) && (flags & GSR_FLAG_NO_COLOR_GRAD)) ? 1 : 0;  // what k_composite_bwd_tiles<false> just wrote
     {
         trace("preprocess_bwd", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_PREPROCESS_BWD, s);

@@ -70,7 +70,7 @@ static_assert(sizeof(GsrSplat) == 48, "splat record must be 48 bytes");
 struct __attribute__((aligned(32))) GsrGradAcc {
     float dr, dg, db, dmx;    // dL/dcolor, dL/dmean2D.x (NDC-scaled)
     float dmy, cxx, cxy, cyy; // dL/dmean2D.y, dL/dconic (xy holds HALF the true off-diagonal gradient, like upstream)
-};                            // dL/dopacity lives in inst_dop[]
+};                            // dL/dopacity lives in inst_dop[] -- or, when nobody asked for dL/dcolour (GsrBwdParams::dop_in_record), in `dr`
 static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte sector");
 
 // Per-bin list ranges as the kernels behind the binning see them.  Two forms (GsrViewExt.bin_capacity):
@@ -535,6 +535,7 @@ struct GsrBwdParams {
     const float *shs, *campos, *cov3D_precomp;  // as in GsrFwdParams
     uint32_t sh_degree, sh_coeffs;
     float *dL_dsh, *dL_dcov3D;  // [rows, sh_coeffs, 3], [rows, 6]: written when the matching input is given
+    int dop_in_record;          // the records were written without colour sums (tile family + GSR_FLAG_NO_COLOR_GRAD): dL/dopacity is their first float, inst_dop is not read
     float fx, fy;               // as in GsrFwdParams: set by gsr_launch_preprocess_bwd
 };
 

@@ -449,9 +449,17 @@ __global__ __launch_bounds__(64, CG ? 2 : GSR_BWD_NOCOLOR_WAVES) void k_composit
             // the record goes to the instance's SLOT (Gaussian-major: scattered stores here, a streaming read in k_preprocess_bwd;
             // scattered reads are what costs on this memory system, gsr_common.h)
             float4 *dst = reinterpret_cast<float4 *>(inst_grad + curRec);  // one whole 32-byte sector
-            dst[0] = make_float4(v0.x, v0.y, v0.z, g_mx);
+            const float dop = S0 * __builtin_amdgcn_rcpf(sop);
+            if (CG) {
+                dst[0] = make_float4(v0.x, v0.y, v0.z, g_mx);
+                inst_dop[curRec] = dop;
+            } else {
+                // without the colour sums three floats of the record are dead: dL/dopacity rides in the first of them -- the record is then ONE
+                // sector instead of a sector + a 4-byte store into inst_dop that costs a sector of its own (round 5 counters, untrained-heads
+                // regime: 98 bytes written per 37-byte record), and k_preprocess_bwd gathers one line per record instead of two
+                dst[0] = make_float4(dop, 0.f, 0.f, g_mx);
+            }
             dst[1] = make_float4(g_my, -0.5f * Sxx, -0.5f * Sxy, -0.5f * Syy);
-            inst_dop[curRec] = S0 * __builtin_amdgcn_rcpf(sop);
             inst_valid[curRec] = 1;
         }
     }

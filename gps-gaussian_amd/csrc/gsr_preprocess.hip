@@ -511,13 +511,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
                         m &= m - 1u;  // (0 stays 0)
                     }
                     float4 a0[4], a1[4];
-                    float a2[4];
+                    float a2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri[u]);
                         a0[u] = r[0];
                         a1[u] = r[1];
-                        a2[u] = inst_dop[ri[u]];
+                        if (!q.dop_in_record) a2[u] = inst_dop[ri[u]];  // (kernel-argument uniform)
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
@@ -527,6 +527,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
                     }
                 }
             }
+        }
+        if (q.dop_in_record) {  // records without colour sums: their first float is dL/dopacity (summed in the same slot order), the other two are zeros
+            g2x = g0.x;
+            g0.x = 0.f;
         }
         const float4 g2 = make_float4(g2x, 0.f, 0.f, 0.f);
         dcol[0] = g0.x; dcol[1] = g0.y; dcol[2] = g0.z;
