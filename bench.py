@@ -33,25 +33,177 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_
 VALU_PEAK_TLANEOPS = 78.6   # 157.3 TFLOP/s fp32 vector = 78.6 T FMA lane-ops/s
 
 
-def stage_bytes(P, R, NB, npix, n_slots=None, n_rec=None):
+def stage_bytes(P, R, NB, npix, n_slots=None, n_rec=None, direct=False, color_grad=True):
     """ALGORITHMIC bytes per launch of every stage (SURVEY.md section 8d convention: each input read once, each intermediate
     written once and read once, each output written once).  R = measured (Gaussian, 8x8-bin) instances, NB = bins, n_slots = gradient-record slots
     (bin-rect cells of all Gaussians), n_rec = slots the compositing backward wrote a record into (<= R).  Unknown counts fall back to R.
-      preprocess      44 P in + 48 P splat record + 16 P bin record + 4 P radii + 8 P slot prefix       = 120 P
-      scan            8 NB counters in (two arrays) + 8 NB offsets / cursors + 4 NB work order            = 20 NB
-      scatter         16 P bin records + 8 R keys + n_slots flag bytes cleared                            = 16 P + 8 R + n_slots
-      sort            8 R keys in + 4 R ids out + 8 NB ranges                                              = 12 R + 8 NB
-      composite_fwd   4 R ids + 36 R splat record fields + 8 NB + 12 Npix image + 8 Npix state            = 40 R + 8 NB + 20 Npix
-      composite_bwd   as the forward's reads + 12 Npix dL/dpix + 8 Npix state, + 37 B per record written  = 40 R + 8 NB + 20 Npix + 37 n_rec
-      preprocess_bwd  n_slots flags + 36 n_rec records + 40 P inputs + 8 P slot prefix + 68 P gradients   = n_slots + 36 n_rec + 116 P"""
+    direct: direct bin lists (round 6) -- no scan / scatter launch, k_preprocess writes the keys, the sort launch carries the scan.
+      preprocess      scanned: 44 P in + 48 P splat record + 16 P bin record + 4 P radii + 8 P slot prefix = 120 P;  direct: 104 P + 8 R keys
+      scan            8 NB counters in (two arrays) + 8 NB offsets / cursors + 4 NB work order            = 20 NB        (scanned lists only)
+      scatter         16 P bin records + 8 R keys                                                          = 16 P + 8 R   (scanned lists only)
+      sort            8 R keys in + 4 R ids out + 8 NB ranges / counts + work order                        = 12 R + 8 NB
+      composite_fwd   4 R ids + 36 R splat record fields + 8 NB + 12 Npix image + 8 Npix state + n_slots flag bytes cleared
+      composite_bwd   as the forward's reads + 12 Npix dL/dpix + 8 Npix state, + 37 B per record written (33 without colour sums: one sector + flag)
+      preprocess_bwd  n_slots flags + 36 n_rec records (32 without colour sums) + 40 P inputs + 8 P slot prefix + 68 P gradients"""
     n_slots = R if n_slots is None else n_slots
     n_rec = R if n_rec is None else n_rec
-    return {"preprocess": 120 * P, "scan": 20 * NB, "scatter": 16 * P + 8 * R + n_slots, "sort": 12 * R + 8 * NB, "composite_fwd": 40 * R + 8 * NB + 20 * npix,
-            "composite_bwd": 40 * R + 8 * NB + 20 * npix + 37 * n_rec, "preprocess_bwd": n_slots + 36 * n_rec + 116 * P}
+    rec_w, rec_r = (37, 36) if color_grad else (33, 32)
+    out = {"preprocess": (104 * P + 8 * R) if direct else 120 * P, "sort": 12 * R + 8 * NB, "composite_fwd": 40 * R + 8 * NB + 20 * npix + n_slots,
+           "composite_bwd": 40 * R + 8 * NB + 20 * npix + rec_w * n_rec, "preprocess_bwd": n_slots + rec_r * n_rec + 116 * P}
+    if not direct:
+        out.update(scan=20 * NB, scatter=16 * P + 8 * R)
+    return out
+
+
+def stage_bound(us, alg_bytes, counter_bytes, valu_instr, sclk_mhz):
+    """What bounds a kernel, from its duration and the separate counter passes: `valu_issue_frac` = wave64 VALU instructions x 4
+    cycles / (1,024 SIMDs x shader clock x t) -- an upper bound of the issue-port use --, `hbm_frac` from the COUNTER bytes when they are known (the
+    algorithmic bytes of a kernel whose re-reads are served by the L2 / Infinity Cache overstate what the HBM sees: the regime's forward compositing
+    read 0.60 by formula, 0.11 by counters), and the name of the larger of the two when it is at least a half -- else "latency" (dependent round
+    trips / occupancy: neither pipe is busy)."""
+    t = us * 1e-6
+    out = {"hbm_frac_algorithmic": round(alg_bytes / t / 1e9 / HBM_PEAK_GBS, 5)}
+    hb = out["hbm_frac_algorithmic"]
+    if counter_bytes:
+        out["hbm_frac_counters"] = hb = round(counter_bytes / t / 1e9 / HBM_PEAK_GBS, 5)
+    out["hbm_frac"] = hb
+    vf = None
+    if valu_instr:
+        vf = out["valu_issue_frac"] = round(valu_instr * 4.0 / (1024 * (sclk_mhz or 2400.0) * 1e6 * t), 4)
+    out["bound"] = "valu issue" if (vf is not None and vf >= 0.5 and vf >= hb) else "hbm" if hb >= 0.5 else "latency (dependent round trips / occupancy)"
+    return out
+
+
+def neighbours_leg(dev, B=4, res=1024, render_res=2048):
+    """The kernels either side of the rasteriser at BASELINE config 4's sizes, each with its ALGORITHMIC bytes, its GPU
+    time and the HBM fraction that gives (until round 5 only speed-ups over eager PyTorch were reported).  Timing: the calls are
+    queued behind a ~2 ms spin kernel so that the GPU runs them back to back, bracketed by two events (no host gaps inside the bracket); a call is
+    one to three launches (the kernels are named).  Backward = (forward + backward) - forward."""
+    import torch
+    from gps_gaussian_amd import corr as K, loss as L, pack as PK, unproject as U
+    out = {}
+
+    def gpu_us(fn, n=10):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(5_000_000)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n * 1e3
+
+    def row(name, kernels, fwd_us, fb_us, fwd_bytes, bwd_bytes, note=""):
+        bwd_us = max(fb_us - fwd_us, 1e-3)
+        out[name] = {"kernels": kernels, "forward": {"us": round(fwd_us, 1), "algorithmic_bytes": int(fwd_bytes), "hbm_frac": round(fwd_bytes / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "backward": {"us": round(bwd_us, 1), "algorithmic_bytes": int(bwd_bytes), "hbm_frac": round(bwd_bytes / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if note:
+            out[name]["note"] = note
+
+    torch.manual_seed(0)
+    # f2: fused L1 + SSIM on the rendered batch [B, 3, 2048, 2048]
+    pred = torch.rand(B, 3, render_res, render_res, device=dev, requires_grad=True)
+    gt = torch.rand(B, 3, render_res, render_res, device=dev)
+    npl = pred.numel()
+
+    def loss_f():
+        with torch.no_grad():
+            L.l1_and_ssim(pred, gt)
+
+    def loss_fb():
+        pred.grad = None
+        l1, ss = L.l1_and_ssim(pred, gt)
+        (0.8 * l1 + 0.2 * (1 - ss)).backward()
+    row("f2_l1_ssim_loss", "k_loss_fwd / k_loss_bwd (csrc/fused_loss.hip)", gpu_us(loss_f), gpu_us(loss_fb), 20 * npl, 24 * npl,
+        "forward: pred + gt in, three derivative maps out; backward: those five in, d_pred out (+ two scalar torch kernels for the weighted sum)")
+    del pred, gt
+    # f3: disparity -> inverse depth -> world points, 2 B views of 1024^2
+    V, S = 2 * B, res
+    flow = torch.rand(V, 1, S, S, device=dev, requires_grad=True)
+    mask = (torch.rand(V, 1, S, S, device=dev) > 0.3).float()
+    intr = torch.tensor([[800.0, 0, S / 2], [0, 800.0, S / 2], [0, 0, 1]], device=dev)[None].repeat(V, 1, 1)
+    extr = torch.eye(4, device=dev)[:3][None].repeat(V, 1, 1).contiguous()
+    tf = torch.full((V,), 120.0, device=dev)
+    gx = torch.randn(V, S * S, 3, device=dev)
+
+    def unp_f():
+        with torch.no_grad():
+            U.unproject(flow, mask, intr, intr, extr, tf)
+
+    def unp_fb():
+        flow.grad = None
+        d, xyz, _ = U.unproject(flow, mask, intr, intr, extr, tf)
+        xyz.backward(gx)
+    npx = V * S * S
+    row("f3_unproject", "k_unproject_fwd / k_unproject_bwd (csrc/unproject.hip)", gpu_us(unp_f), gpu_us(unp_fb), 25 * npx, 24 * npx)
+    # f1: mask compaction + pack of B stereo pairs
+    data = {}
+    for v in ("lmain", "rmain"):
+        data[v] = dict(xyz=torch.randn(B, S * S, 3, device=dev, requires_grad=True), img=torch.rand(B, 3, S, S, device=dev),
+                       rot_maps=torch.randn(B, 4, S, S, device=dev, requires_grad=True), scale_maps=torch.rand(B, 3, S, S, device=dev, requires_grad=True),
+                       opacity_maps=torch.rand(B, 1, S, S, device=dev, requires_grad=True), pts_valid=(torch.rand(B, S * S, device=dev) < 0.286))
+    rows_n = int(sum(int(data[v]["pts_valid"].sum()) for v in data))
+
+    def pack_f():
+        with torch.no_grad():
+            PK.pack_views(data)
+
+    def pack_fb():
+        for v in data:
+            for k in ("xyz", "rot_maps", "scale_maps", "opacity_maps"):
+                data[v][k].grad = None
+        o = PK.pack_views(data)
+        (o[0].sum() + o[2].sum() + o[3].sum() + o[4].sum()).backward()
+    row("f1_pack_views", "k_pack_count / k_pack_scan / k_pack_write, k_pack_bwd (csrc/pack_views.hip)", gpu_us(pack_f), gpu_us(pack_fb),
+        61 * npx + 56 * rows_n, 48 * npx + 56 * rows_n, "%d of %d pixels valid; the backward leg includes four torch sum-backward fills" % (rows_n, npx))
+    del data
+    # f4: correlation volume + pyramid, lookup of all levels, convex upsampling (RAFT-Stereo shapes for B pairs at 1024^2)
+    N, D, H, W, f = 2 * B, 192, res // 8, res // 8, 8
+    f1 = torch.randn(N, D, H, W, device=dev, requires_grad=True)
+    f2 = torch.randn(N, D, H, W, device=dev, requires_grad=True)
+    coords = torch.rand(N, 2, H, W, device=dev) * W
+    pyr_b = 4 * N * H * W * (W + W // 2 + W // 4 + W // 8)
+    blk = [None]
+
+    def cv_f():
+        with torch.no_grad():
+            blk[0] = K.CorrBlockFast1D(f1, f2, num_levels=4, radius=4)
+
+    def cv_fb():
+        f1.grad = f2.grad = None
+        b_ = K.CorrBlockFast1D(f1, f2, num_levels=4, radius=4)
+        sum(v.sum() for v in b_.volumes).backward()
+    row("f4_corr_volume_pyramid", "k_cv_build / k_cv_build_bwd (csrc/corr_pyramid.hip, fp32 MFMA)", gpu_us(cv_f), gpu_us(cv_fb), 2 * 4 * N * D * H * W + pyr_b,
+        pyr_b + 4 * 4 * N * D * H * W, "2 N H W1 W2 D = %.1f GFLOP per direction on the fp32 matrix path as well (157 TFLOP/s peak)" % (2e-9 * N * H * W * W * D))
+    cv_f()
+
+    def lk_f():
+        with torch.no_grad():
+            blk[0](coords)
+    us_lk = gpu_us(lk_f)
+    out["f4_lookup_all_levels"] = {"kernels": "k_cs_lookup (one launch for four levels)", "forward": {"us": round(us_lk, 1), "algorithmic_bytes": 4 * N * H * W * (1 + 36 + 4 * 2 * 9),
+                                                                                                     "hbm_frac": round(4 * N * H * W * (1 + 36 + 72) / (us_lk * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                                   "note": "gathers 2 x 9 taps per level from a pyramid that sits in the Infinity Cache: latency-bound, listed for completeness"}
+    mask_u = torch.randn(N, 9 * f * f, H, W, device=dev, requires_grad=True)
+    flw = torch.randn(N, 2, H, W, device=dev, requires_grad=True)
+
+    def up_f():
+        with torch.no_grad():
+            K.upsample_flow(flw, mask_u, f)
+
+    def up_fb():
+        mask_u.grad = flw.grad = None
+        K.upsample_flow(flw, mask_u, f).sum().backward()
+    nm, no = mask_u.numel(), N * 2 * f * H * f * W
+    row("f4_convex_upsample", "k_up_fwd / k_up_bwd (csrc/corr_pyramid.hip)", gpu_us(up_f), gpu_us(up_fb), 4 * (nm + flw.numel() + no), 4 * (2 * nm + no + 2 * flw.numel()))
+    torch.cuda.empty_cache()
+    return out
 
 
 def counter_traffic(fname, P, W, H, R):
-    """Per-stage HBM traffic from the separate rocprofv3 --pmc passes (tools/prof_r05.sh -> profiles/<fname>, which records the workload it was
+    """Per-stage HBM traffic from the separate rocprofv3 --pmc passes (tools/prof_r06.sh -> profiles/<fname>, which records the workload it was
     measured on); {} unless THIS run is that workload (same P, size, R within 1 %)."""
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", fname)))
@@ -208,7 +360,7 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         torch.cuda.synchronize(dev)
         n_rec, n_slots = int(cnt[0]), int(cnt[1])
         out["gradient_records"] = {"slots": n_slots, "written": n_rec}
-        alg = stage_bytes(P, R, NB, npix, n_slots, n_rec)
+        alg = stage_bytes(P, R, NB, npix, n_slots, n_rec, direct=bool(sess0.bin_cap))
         RZ.set_stage_timing(True)
         run("train", 1, 3)
         torch.cuda.synchronize(dev)
@@ -218,15 +370,38 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
         RZ.set_stage_timing(False)
         tab = {}
         traffic = counter_traffic("pmc_traffic_regime.json", P, render_res, render_res, R)
+        try:
+            sclk = _capi.measure_sclk_mhz(dev)
+        except Exception:  # noqa: BLE001
+            sclk = None
         for k, (ms, n) in st.items():
-            if n:
+            if n and k in alg:
                 us = ms / n * 1e3
-                tab[k] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": alg[k], "hbm_frac": round(alg[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
-                tr = traffic.get(k, {}).get("hbm_bytes_per_launch")
+                tab[k] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": alg[k]}
+                pm = traffic.get(k, {})
+                tr = pm.get("hbm_bytes_per_launch")
                 if tr:
                     tab[k].update(counter_bytes=tr, counter_gbs=round(tr / (us * 1e-6) / 1e9, 1), traffic_ratio=round(tr / alg[k], 3))
+                tab[k].update(stage_bound(us, alg[k], tr, pm.get("valu_wave_instructions_per_launch"), sclk))  # hbm_frac: from the COUNTER bytes when they are known
         out["stages_one_view_in_flight"] = tab
         out["stages_sum_us"] = round(sum(v["avg_us"] for v in tab.values()), 1)
+        # the same table for the gradient set stage 2 differentiates (no dL/dcolour): the two backward kernels are other instantiations -- one-sector
+        # records that carry dL/dopacity (round 6)
+        run("train", 1, 3, color_grad=False)
+        torch.cuda.synchronize(dev)
+        cnt.zero_()
+        _capi.check(_capi.lib().gsr_debug_count_records(sess0.ws.data_ptr(), sess0.ws.numel(), P, render_res, render_res, sess0.cap, sess0.bin_cap, cnt.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream), "gsr_debug_count_records")
+        torch.cuda.synchronize(dev)
+        alg2 = stage_bytes(P, R, NB, npix, int(cnt[1]), int(cnt[0]), direct=bool(sess0.bin_cap), color_grad=False)
+        RZ.set_stage_timing(True)
+        _capi.timing_read()
+        run("train", 1, max(10, steps), color_grad=False)
+        st2 = _capi.timing_read()
+        RZ.set_stage_timing(False)
+        out["stages_stage2_gradient_set"] = {k: dict(avg_us=round(st2[k][0] / st2[k][1] * 1e3, 2), algorithmic_bytes=alg2[k],
+                                                     hbm_frac_algorithmic=round(alg2[k] / (st2[k][0] / st2[k][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
+                                             for k in ("composite_bwd", "preprocess_bwd") if st2.get(k, (0, 0))[1]}
         out["longest_bin_list"] = int(RZ._dev_state(dev).get("longest", 0))
     return out
 
@@ -294,56 +469,6 @@ def full_pipeline_leg(budget_s):
     return out
 
 
-def graph_leg(args):
-    """Secondary measurement, run by the main bench in a CHILD process (a HIP runtime that mis-handles a capture takes the
-    process down, and the headline line must survive that): the same forward + backward step captured once into a HIP graph
-    (GPSGS_CHECK=none: launches + one memset, nothing read back) and replayed --steps times."""
-    import torch
-    import gps_gaussian_amd  # noqa: F401
-    from gps_gaussian_amd import synthetic as S
-    from gps_gaussian_amd import rasterizer as RZ
-    dev = torch.device("cuda", 0)
-    render_res = args.render_res or args.res
-    smp = S.make_stereo_sample(args.res, args.gaussians, seed=S.SEED, render_res=render_res)
-    g = S.compact_sample(smp)
-    cam = smp["novel_view"]
-    names = ("means3D", "colors", "opacities", "scales", "rotations")
-    st = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    with torch.cuda.stream(st):  # leaves, seed gradient, warm-up and capture all on ONE stream (no cross-stream autograd syncs)
-        t = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in names}
-        m2 = torch.zeros_like(t["means3D"], requires_grad=True)
-        rs = RZ.GaussianRasterizationSettings(
-            image_height=render_res, image_width=render_res, tanfovx=math.tan(float(cam["FovX"]) * 0.5), tanfovy=math.tan(float(cam["FovY"]) * 0.5),
-            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=torch.from_numpy(cam["world_view_transform"]).to(dev),
-            projmatrix=torch.from_numpy(cam["full_proj_transform"]).to(dev), sh_degree=3,
-            campos=torch.from_numpy(cam["camera_center"]).to(dev), prefiltered=False, debug=False)
-        rast = RZ.GaussianRasterizer(rs)
-        gout = torch.randn(3, render_res, render_res, device=dev)
-
-        def step():
-            img, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=None, colors_precomp=t["colors"],
-                          scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
-            return torch.autograd.grad(img, [t[k] for k in names] + [m2], gout)
-
-        step()  # sync mode: learns the capacity
-        os.environ["GPSGS_CHECK"] = "none"
-        step()
-        st.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=st):
-            step()
-        for _ in range(5):
-            graph.replay()
-        st.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            graph.replay()
-        st.synchronize()
-        dt = time.perf_counter() - t0
-    print(json.dumps({"graph_replay_views_per_s": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps}))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -357,15 +482,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary `configs` block (config 2 rendered at 2048^2, config 5)")
     ap.add_argument("--headline-only", action="store_true",
-                    help="skip every secondary leg (autograd module, forward only, deferred check, stage-2 path, HIP graph, CPU rows): with --inflight 1 "
+                    help="skip every secondary leg (Python host path, forward only, deferred check, stage-2 path, neighbours, CPU rows): with --inflight 1 "
                          "every kernel launch of the run then has the chip to itself (tools/prof_r04.sh profiles that mode for the exclusive durations)")
-    ap.add_argument("--graph-leg", action="store_true", help="(internal) time HIP-graph replays of the fwd+bwd step and print one JSON line")
     ap.add_argument("--no-full-pipeline", action="store_true", help="skip the `full_pipeline` leg (BASELINE configs 3 / 4 with the reference's own scripts and networks)")
     ap.add_argument("--full-pipeline-budget", type=float, default=600.0, help="seconds the full-pipeline leg may take in total; what does not fit is skipped and says so")
     args = ap.parse_args()
-    if args.graph_leg:
-        return graph_leg(args)
-
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -413,11 +534,12 @@ def main():
     # ONE rank: the GPU legs run pinned to eight CPUs of one L3 domain next to the GPU (dist.pin_near_gpu: what INTEGRATION.md tells a training
     # script to do -- the plugin path is ~240 us of two-thread host work per 250 us GPU step, and a scheduler that migrates it across a 256-CPU box
     # makes it ~40 % slower); the CPU-heavy legs (full pipeline children, the OpenMP baseline) run with the original mask again
+    # ONE rank: nothing is pinned while `value` is measured (round 6: the reference's scripts do not pin, and the compiled host path -- csrc/host_shim.cpp -- has
+    # taken the Python / PyTorch host work that made the step host-bound on some boxes); the same step pinned to eight CPUs of one L3 domain next to
+    # the GPU (dist.pin_near_gpu) is measured right behind it and reported as `plugin_api_pinned_views_per_s`
     pinned_one_rank = False
-    if cpu_slice is None and world == 1:
-        cpu_slice = D.pin_near_gpu(local_rank)
-        pinned_one_rank = cpu_slice is not None
     _capi.lib()  # fail loudly if the HIP library is missing
+    assert RZ._fast_module(), "bench.py: the compiled host path (lib/_gpsgs_fast.so) is missing -- run __graft_entry__.build()"
 
     # ---- synthetic workload: one stereo pair per rank (different pose per rank), resident in HBM ------------------
     render_res = args.render_res or args.res
@@ -593,6 +715,31 @@ def main():
         sclk_mhz = round(_capi.measure_sclk_mhz(dev), 1)  # shader clock under VALU load, measured (not the 2.4 GHz maximum)
     except Exception:  # noqa: BLE001
         sclk_mhz = None
+    # COLD variant of the one-view step: every timed step above re-renders the same view, whose ~0.3 GB of workspace and inputs
+    # largely survive in the 256 MB Infinity Cache from one step to the next; in training the networks stream gigabytes between two renders.  Here a
+    # 1 GiB device fill runs between steps, OUTSIDE the event bracket of the step; the warm figure is taken the same way (events, no fill) for comparison.
+    cold = None
+    if not args.headline_only:
+        try:
+            evict = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+
+            def event_ms(n, fill):
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+                for a_, b_ in ev:
+                    if fill:
+                        evict.fill_(1)
+                    a_.record(); step(); b_.record()
+                torch.cuda.synchronize(dev)
+                return sorted(a_.elapsed_time(b_) for a_, b_ in ev)[n // 2]
+
+            event_ms(5, True)
+            ms_cold, ms_warm = event_ms(25, True), event_ms(25, False)
+            cold = {"single_view_cold_views_per_s": round(1e3 / ms_cold, 1), "single_view_warm_same_method_views_per_s": round(1e3 / ms_warm, 1),
+                    "ms_cold": round(ms_cold, 4), "ms_warm": round(ms_warm, 4),
+                    "how": "median of 25 C-ABI session steps, each bracketed by two events; cold: a 1 GiB device fill between steps, outside the bracket"}
+            del evict
+        except Exception as e:  # noqa: BLE001
+            cold = {"error": repr(e)[:200]}
     # secondary: the stage-2 gradient set (no dL/dcolour), same sessions; the dominant kernel keeps its bracket for the exclusive duration
     s2 = None
     if not args.headline_only:
@@ -621,6 +768,19 @@ def main():
     q1, q3 = sorted(api_blocks)[REPEATS // 4], sorted(api_blocks)[(3 * REPEATS) // 4]
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
+    # ... and the same blocks with the process pinned next to its GPU (one rank only; the remaining GPU legs keep the pin, the CPU legs drop it)
+    el_pinned = None
+    if cpu_slice is None and world == 1:
+        cpu_slice = D.pin_near_gpu(local_rank)
+        pinned_one_rank = cpu_slice is not None
+        if pinned_one_rank:
+            el_pinned = sorted(timed(fwd_bwd, args.steps, 5 if i == 0 else 0) for i in range(5))[2]
+    # the Python host path (GPSGS_FAST=0: rasterizer.py's autograd Function, what rounds 1-5 measured), same pinning state as the line above
+    el_pyhost = None
+    if not args.headline_only:
+        os.environ["GPSGS_FAST"] = "0"
+        el_pyhost = sorted(timed(fwd_bwd, args.steps, 5 if i == 0 else 0) for i in range(5))[2]
+        os.environ["GPSGS_FAST"] = "1"
 
     # secondary numbers: forward only, and the non-blocking check mode, through the same module
     el_fwd = el_def = el_fwd_def = None
@@ -644,6 +804,15 @@ def main():
         R_tile = int((((x1 - x0) * (y1 - y0)).long() * (sess.radii > 0)).sum().item())
     except Exception:  # noqa: BLE001
         R_tile = None
+
+    # ---- secondary: the kernels either side of the rasteriser (rows f1-f4) with algorithmic bytes and HBM fractions -------------------------------
+    neighbours = None
+    if rank == 0 and world == 1 and not args.headline_only:
+        try:
+            neighbours = neighbours_leg(dev)
+        except Exception as e:  # noqa: BLE001
+            neighbours = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
 
     # ---- secondary: the hot path inside one stage-2 training iteration (BASELINE config 4: batch = 4 stereo pairs per GPU) ----
     stage2 = None if args.headline_only else stage2_leg(args, s, dev, rank, local_rank, world, D, timed)
@@ -673,11 +842,7 @@ def main():
     # (rank 0, N = 1; the reference build under oracle/_ref is the CALLER of the product here, executed by tools/run_reference.py in child processes)
     full_pipeline = None
     D.restore_affinity()  # (a no-op unless pin_near_gpu() pinned this rank: everything below is CPU-heavy or runs in child processes)
-    # for the record: the headline's step once more with every thread of the process back on all CPUs (what an unpinned training script gets on THIS
-    # box at THIS moment: host-bound on some boxes, profiles/r05_host_timeline.md) -- five blocks, the median
-    el_unpinned = None
-    if pinned_one_rank and not args.headline_only:
-        el_unpinned = sorted(timed(fwd_bwd, args.steps, 5 if i == 0 else 0) for i in range(5))[2]
+    el_unpinned = elapsed  # (`value` itself is the unpinned figure since round 6)
     if rank == 0 and world == 1 and not args.headline_only and not args.no_full_pipeline and (args.res, args.gaussians, W) == (1024, 600000, 1024):
         torch.cuda.empty_cache()  # (the default workload only, like `configs`: a small functional run of bench.py does not start full-size networks)
         full_pipeline = full_pipeline_leg(args.full_pipeline_budget)
@@ -706,17 +871,19 @@ def main():
         n_rec, n_slots = int(cnt[0]), int(cnt[1])
     except Exception:  # noqa: BLE001
         n_slots = n_rec = None
-    alg_bytes = stage_bytes(P, R, NB, npix, n_slots, n_rec)
+    alg_bytes = stage_bytes(P, R, NB, npix, n_slots, n_rec, direct=bool(sess.bin_cap))
     traffic_all = counter_traffic("pmc_traffic.json", P, W, H, R)
     per_stage = {}
     for name, (ms, n) in stages.items():
-        if n:
+        if n and name in alg_bytes:
             avg_ms = ms / n
             per_stage[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": n, "algorithmic_bytes": alg_bytes[name],
                                "hbm_gbs": round(alg_bytes[name] / (avg_ms * 1e-3) / 1e9, 1)}
-            tr_ = traffic_all.get(name, {}).get("hbm_bytes_per_launch")
+            pm_ = traffic_all.get(name, {})
+            tr_ = pm_.get("hbm_bytes_per_launch")
             if tr_:  # L2-miss traffic of the same workload from the separate counter passes: 2 x FETCH_SIZE + WRITE_SIZE (profiles/pmc_traffic.json)
                 per_stage[name].update(counter_bytes=tr_, counter_gbs=round(tr_ / (avg_ms * 1e-3) / 1e9, 1), traffic_ratio=round(tr_ / alg_bytes[name], 3))
+            per_stage[name].update(stage_bound(avg_ms * 1e3, alg_bytes[name], tr_, pm_.get("valu_wave_instructions_per_launch"), sclk_mhz))
     dom = max(per_stage, key=lambda k: per_stage[k]["avg_us"]) if per_stage else None
     roofline = None
     if dom:
@@ -744,7 +911,7 @@ def main():
                     "algorithmic_bytes": "SURVEY.md section 8(d): 40 R + 8 T + 20 Npix + 44 P with R = instances on upstream's 16x16 tiles (T tiles)",
                     "launches_averaged": int(dom_excl[1]) if dom == dom_stage else None,
                     "measured": "hipEvents around the kernel on its launch stream: the median of %d timed blocks of %d steps each with ONE view in flight (exclusive "
-                                "duration; profiles/r05_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % (N_SINGLE_BLOCKS, n_single),
+                                "duration; profiles/r06_kernel_stats_one_view.md is the rocprofv3 summary of the same mode)" % (N_SINGLE_BLOCKS, n_single),
                     "bound_note": "the contract's roofline is HBM; this kernel's HBM fraction is low by construction (>= 50 op/B: SURVEY.md section 8d says the same).  At config 2 it is "
                                   "bound by instruction issue per SIMD at the occupancy its registers allow (DESIGN.md section 4: counters, occupancy sweep, per-workgroup timeline)",
                     # the same kernel with F views in flight (C-ABI sessions): launches of different views overlap and time-share the chip
@@ -803,19 +970,6 @@ def main():
         except Exception as e:  # noqa: BLE001
             cpu_splat = {"error": repr(e)[:200]}
 
-    # ---- secondary: the same step replayed from a HIP graph (child process; see graph_leg) --------------------------------
-    graph_res = None
-    if rank == 0 and world == 1 and not args.headline_only:
-        import subprocess
-        try:
-            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-leg", "--steps", str(args.steps), "--res", str(args.res),
-                                 "--gaussians", str(args.gaussians)] + (["--render-res", str(args.render_res)] if args.render_res else []),
-                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
-            lines = [x for x in cp.stdout.splitlines() if x.startswith("{")]
-            graph_res = json.loads(lines[-1]) if (cp.returncode == 0 and lines) else {"error": "child exited with %d" % cp.returncode}
-        except Exception as e:  # noqa: BLE001
-            graph_res = {"error": repr(e)[:200]}
-
     if rank == 0:
         rate = lambda el: round(world * args.steps / el, 2) if el else None  # noqa: E731
         cfg_name = ("BASELINE config 2" if (args.res, args.gaussians, W) == (1024, 600000, 1024) else
@@ -843,19 +997,24 @@ def main():
             "single_view_in_flight_views_per_s": round(world * n_single / el_single, 2),
             "autograd_api_views_per_s": round(value, 2),
             "cpu_affinity": ({"rank0_cpus": len(cpu_slice), "cpus": sorted(cpu_slice)[:16],
-                              "how": ("dist.pin_near_gpu: one L3 domain on the GPU's NUMA node, GPU legs only" if pinned_one_rank else "dist.set_cpu_affinity: this rank's slice")}
+                              "how": ("NOT pinned while `value` was measured; dist.pin_near_gpu (one L3 domain on the GPU's NUMA node) for plugin_api_pinned_views_per_s and the "
+                                      "GPU legs behind it" if pinned_one_rank else "dist.set_cpu_affinity: this rank's slice")}
                              if cpu_slice else "not set (GPSGS_AFFINITY=0, no sched_setaffinity, or no topology information)"),
-            "not_measured_at_this_world_size": ([] if world == 1 else ["configs", "full_pipeline", "cpu_baseline", "cpu_taichi_splat_port", "hip_graph_replay"]),
+            "not_measured_at_this_world_size": ([] if world == 1 else ["configs", "full_pipeline", "cpu_baseline", "cpu_taichi_splat_port", "neighbours"]),
             "stage2_gradient_set": s2,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_taichi_splat_port": cpu_splat,
             "forward_only_views_per_s": rate(el_fwd),
             "deferred_check_views_per_s": {"fwd_bwd": rate(el_def), "fwd": rate(el_fwd_def)},
             "plugin_api_unpinned_views_per_s": rate(el_unpinned),
+            "plugin_api_pinned_views_per_s": rate(el_pinned),
+            "plugin_api_python_host_path_views_per_s": rate(el_pyhost),
+            "host_path": "compiled (lib/_gpsgs_fast.so: csrc/host_shim.cpp, a C++ autograd Function over the same C-ABI); GPSGS_FAST=0 selects the Python one",
             "stages": per_stage,
+            "single_view_cold": cold,
+            "neighbours": neighbours,
             "stage2_path": stage2,
             "configs": configs,
             "full_pipeline": full_pipeline,
-            "hip_graph_replay": graph_res,
         }
         print(json.dumps(line))
     D.shutdown()

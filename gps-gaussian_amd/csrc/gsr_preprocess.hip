@@ -437,7 +437,10 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) __attribute__((amdgpu_num_sgpr(GSR
     if (i < q.P) binrec[i] = make_uint4(__float_as_uint(depth_out), rlo, rhi, mask);
 }
 
-template <bool APPEAR>  // as k_preprocess: true = SH colours and / or precomputed covariances among the inputs
+// APPEAR as k_preprocess: true = SH colours and / or precomputed covariances among the inputs.  DOPREC: the records were written without colour sums
+// (GsrBwdParams::dop_in_record): dL/dopacity is their first float and inst_dop is not read -- a template parameter, not a run-time test: with the test
+// inside the four-record gather the common instantiation went 28.7 -> 32.6 us (the conditional loads split the batch of twelve into two waits).
+template <bool APPEAR, bool DOPREC>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const GsrSplat *__restrict__ splats,
                                                         const uint32_t *__restrict__ goff, const uint32_t *__restrict__ gpart,
                                                         const uint8_t *__restrict__ inst_valid, const float *__restrict__ inst_dop,
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
                         const float4 *r = reinterpret_cast<const float4 *>(inst_grad + ri[u]);
                         a0[u] = r[0];
                         a1[u] = r[1];
-                        if (!q.dop_in_record) a2[u] = inst_dop[ri[u]];  // (kernel-argument uniform)
+                        if (!DOPREC) a2[u] = inst_dop[ri[u]];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(GsrBwdParams q, const Gs
                 }
             }
         }
-        if (q.dop_in_record) {  // records without colour sums: their first float is dL/dopacity (summed in the same slot order), the other two are zeros
+        if (DOPREC) {  // records without colour sums: their first float is dL/dopacity (summed in the same slot order), the other two are zeros
             g2x = g0.x;
             g0.x = 0.f;
         }
@@ -733,8 +736,10 @@ void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, co
     GsrBwdParams q = p;
     q.fx = (float)q.W / (2.f * q.tanfovx);
     q.fy = (float)q.H / (2.f * q.tanfovy);
-    if (q.shs || q.cov3D_precomp)
-        hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
-    else
-        hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3((q.P + 255) / 256), dim3(256), 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    const dim3 grid((q.P + 255) / 256), block(256);
+    const bool appear = q.shs || q.cov3D_precomp;
+    if (appear && q.dop_in_record) hipLaunchKernelGGL((k_preprocess_bwd<true, true>), grid, block, 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    else if (appear) hipLaunchKernelGGL((k_preprocess_bwd<true, false>), grid, block, 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    else if (q.dop_in_record) hipLaunchKernelGGL((k_preprocess_bwd<false, true>), grid, block, 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
+    else hipLaunchKernelGGL((k_preprocess_bwd<false, false>), grid, block, 0, s, q, splats, goff, gpart, inst_valid, inst_dop, inst_grad, hdr);
 }

@@ -17,6 +17,7 @@
 #include <torch/csrc/autograd/custom_function.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -59,6 +60,7 @@ void release_slot(int dev, int slot) {
 struct Header {
     long long R = 0, nbytes = 0;
     unsigned overflow = 0, longest = 0, slots = 0, npts = 0;
+    double wait_us = 0.0;  // time spent spinning on the notification word (the GPU's share of the forward call: tools/host_time.py subtracts it)
 };
 thread_local Header t_hdr;
 
@@ -100,6 +102,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         // the device publishes the header to the pinned slot right after the binning: the host checks capacity while sort / compositing still run
         unsigned long n = 0;
         bool lost = false;
+        const auto t_wait0 = std::chrono::steady_clock::now();
         while (w32[7] != seq) {
             if ((++n & 0x3fffu) == 0 && stream.query()) {  // the stream drained without the store: surface it instead of spinning for ever
                 if (w32[7] == seq) break;
@@ -108,6 +111,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
             }
         }
         Header h;
+        h.wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_wait0).count();
         h.R = (long long)((unsigned long long)w32[0] | ((unsigned long long)w32[1] << 32));
         h.overflow = w32[2]; h.longest = w32[3]; h.slots = w32[5]; h.npts = w32[6];
         h.nbytes = (long long)nbytes;
@@ -191,7 +195,7 @@ py::object rasterize(const Tensor &means3D, const Tensor &means2D, const Tensor 
 
 py::tuple last_header() {
     const Header &h = t_hdr;
-    return py::make_tuple(h.R, h.overflow, h.longest, h.slots, h.npts, h.nbytes);
+    return py::make_tuple(h.R, h.overflow, h.longest, h.slots, h.npts, h.nbytes, h.wait_us);
 }
 
 int slots_in_flight(int dev) {

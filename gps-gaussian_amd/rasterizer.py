@@ -743,7 +743,7 @@ def _fast_forward(means3D, means2D, opacities, colors_precomp, scales, rotations
                       float(rs.tanfovy), float(rs.scale_modifier), cap, bin_cap, st.get("longest", 0), flags)
     if out is None:
         return None
-    R, overflow, longest, slots, npts, nbytes = F.last_header()
+    R, overflow, longest, slots, npts, nbytes, _wait_us = F.last_header()
     st["last_ws_bytes"] = nbytes
     _learn(st, R, max(R, slots), P, longest)
     _note_longest(st, longest)

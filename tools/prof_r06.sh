@@ -6,7 +6,7 @@
 #   regime  FETCH_SIZE / WRITE_SIZE / kernel trace of the untrained-heads regime (bench.py's config3_regime leg: P = 550,000, 2048^2, scales at their clamp)
 # tools/make_profiles.py then writes <tag>_kernel_stats.md, <tag>_kernel_stats_one_view.md, <tag>_pmc_summary.md, pmc_traffic.json,
 # <tag>_regime_pmc_summary.md and pmc_traffic_regime.json (each with the workload it was measured on) into gpurun_out/prof_<tag>/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -15,7 +15,7 @@ cd /tmp
 CMD="python $ROOT/bench.py --steps 12 --warmup 3 --repeats 5 --no-cpu-baseline --no-configs --no-full-pipeline"
 ONE="$CMD --inflight 1 --headline-only"
 REG="python $ROOT/tools/stage_times.py --families tiles --steps 10 --res 1024 --render-res 2048 --gaussians 550000 --attributes untrained --seed-offset 77"
-KRE='k_composite|k_preprocess|k_scatter|k_sort|k_scan'
+KRE='k_composite|k_preprocess|k_scatter|k_sort|k_scan|k_zero16'
 timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace1 -o t -- $ONE > $OUT/trace1.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-include-regex "$KRE" -f csv -d $OUT/pmc_sq -o p -- $ONE > $OUT/pmc_sq.log 2>&1
