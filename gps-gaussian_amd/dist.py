@@ -161,7 +161,7 @@ def pin_near_gpu(device_index=0, n_cpus=8):
     """ONE process driving one GPU through the autograd API (the reference's train_stage2.py, bench.py's `value`): pin the calling thread -- and every
     thread it starts afterwards: the autograd engine's worker, the loader's -- to n_cpus CPUs of ONE L3 domain on the GPU's NUMA node, the least busy
     domain right now.  A step of the drop-in rasteriser is ~250 us of GPU work fed by ~240 us of Python / PyTorch host work spread over two threads
-    (tools/host_timeline.py); left to the scheduler on a 256-CPU box that host work migrates between cores and sockets and runs ~40 % slower (measured
+    (tools/host_time.py; round 5: profiles/r05_host_timeline.md); left to the scheduler on a 256-CPU box that host work migrates between cores and sockets and runs ~40 % slower (measured
     on one box, same run: forward prologue 73 -> 42 us, notification -> backward launched 82 -> 50 us, backward launched -> next forward launched
     153 -> 100 us; the step went from host-bound, 272 us, to GPU-bound, 252 us).  Pinning to the whole NUMA node does NOT do it (257 us): it is the
     shared L3 and the absence of migrations that count.  GPSGS_AFFINITY=0 switches it off.  restore_affinity() undoes it (CPU-heavy legs: an OpenMP

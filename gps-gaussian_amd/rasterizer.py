@@ -672,7 +672,7 @@ def _backward_impl(ctx, saved, grad_out_color, arena, color_grad=True):
         else:
             # one allocation, six contiguous gradient arrays carved out of it (quaternion gradient first: it is stored as float4)
             # (ONE split + six views: the slice-then-view form was twelve tensor operations, ~25 us of host time on the path between the capacity
-            #  notification and the backward's launch -- the stretch that decides whether a slower host keeps the GPU fed, tools/host_cprofile.py)
+            #  notification and the backward's launch -- the stretch that decides whether a slower host keeps the GPU fed, profiles/r05_host_timeline.md)
             buf = torch.empty((P * 17,), dtype=torch.float32, device=dev)
             b_rot, b_m3, b_m2, b_col, b_sc, b_op = buf.split_with_sizes((4 * P, 3 * P, 3 * P, 3 * P, 3 * P, P))
             d_rot, d_m3, d_m2 = b_rot.view(P, 4), b_m3.view(P, 3), b_m2.view(P, 3)
@@ -725,8 +725,8 @@ def _fast_forward(means3D, means2D, opacities, colors_precomp, scales, rotations
     F = _fast_module()
     env = os.environ
     if (not F or rs.debug or _extra_flags or _deferred_list() is not None or env.get("GPSGS_CHECK", "sync") != "sync" or not _early_notify
-            or env.get("GPSGS_DUMP_INPUTS") or not isinstance(means3D, torch.Tensor) or not means3D.is_cuda):
-        return None
+            or env.get("GPSGS_DUMP_INPUTS") or not isinstance(means3D, torch.Tensor) or not means3D.is_cuda or torch.cuda.is_current_stream_capturing()):
+        return None  # (under graph capture the Python path says what to do instead of spinning on a header that never arrives)
     dev = means3D.device
     st = _dev_state(dev)
     if st["pending"]:

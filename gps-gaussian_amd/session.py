@@ -6,7 +6,7 @@ What it is NOT: a different code path.  It enqueues exactly the kernels `rasteri
 two C-ABI entry points (gsr_forward_notify, gsr_backward), with the same exact capacity policy (the binning scan publishes the
 instance count to pinned host memory; an overflow is repaired by a transparent re-run).  What it leaves out is what PyTorch adds
 around them per call: the autograd Function / engine round trip (~120 us per forward+backward on an idle MI355X host, measured
-with tools/host_profile.py), tensor allocations (outputs, workspace and gradient buffers are allocated once per (P, W, H)) and
+round 3; tools/host_time.py measures the module paths today), tensor allocations (outputs, workspace and gradient buffers are allocated once per (P, W, H)) and
 argument normalisation.  Host cost per forward+backward: two ctypes calls (~35 us, almost all of it the HIP launches themselves).
 
 Semantics follow the reference call at /root/reference/gaussian_renderer/__init__.py:36-62 (precomputed colours, scales + rotations).

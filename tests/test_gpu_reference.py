@@ -98,10 +98,10 @@ def test_reference_pts2render_runs_on_the_hip_rasteriser(cams, bg):
             return img.detach(), {v: {k: data[v][k].grad.clone() for k in keys} for v in ("lmain", "rmain")}
 
         calls = []
-        real = RZ._RasterizeGaussians.forward
-        RZ._RasterizeGaussians.forward = staticmethod(lambda ctx, *a, **k: (calls.append(1), real(ctx, *a, **k))[1])
+        real = RZ.GaussianRasterizer.forward             # (the module's entry: behind it the compiled host path or the Python one, whichever applies)
+        RZ.GaussianRasterizer.forward = lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1]
         img_r, g_r = run(GR.pts2render)                  # the REFERENCE's pts2render -> the reference's render -> HIP kernels
-        RZ._RasterizeGaussians.forward = real
+        RZ.GaussianRasterizer.forward = real
         assert len(calls) == B
         img_m, g_m = run(render_api.pts2render_unfused)
         img_f, g_f = run(render_api.pts2render)

@@ -153,16 +153,26 @@ def interp(args):
     TVI.pts2render = clk.wrap("pts2render", TVI.pts2render)
     GR.render = clk.wrap("render", GR.render)
     Ps = []
-    real_fwd = RZ._forward_impl
+    real_fwd = RZ.GaussianRasterizer.forward  # the module's entry: behind it the compiled host path or the Python one, whichever applies
 
-    def spy(ctx, means3D, *a, **k):
+    def spy(self, means3D, *a, **k):
         Ps.append(int(means3D.shape[0]))
-        return real_fwd(ctx, means3D, *a, **k)
-    RZ._forward_impl = spy
+        return real_fwd(self, means3D, *a, **k)
+    RZ.GaussianRasterizer.forward = spy
+    real_impl = RZ._forward_impl              # (with GPSGS_ACCELERATE=pack the batch node calls _forward_impl itself: row-range views)
+
+    def spy_impl(ctx, means3D, *a, **k):
+        rows = k.get("rows")
+        Ps.append(int(rows.capacity if rows is not None else means3D.shape[0]))
+        return real_impl(ctx, means3D, *a, **k)
+    RZ._forward_impl = spy_impl
     del stamps[:]
     r.infer_static(view_select=[0, 1], novel_view_nums=args.views)
     tot = clk.totals(skip=1)
-    RZ._forward_impl = real_fwd
+    RZ.GaussianRasterizer.forward = real_fwd
+    RZ._forward_impl = real_impl
+    if not Ps:
+        Ps.append(0)
     out["gpu_ms_per_view"] = {k: v[0] for k, v in tot.items()}
     if "render" in tot:  # (with GPSGS_ACCELERATE=pack the reference's render() is not on the path: pts2render is the fused pack + batch node)
         out["gpu_ms_per_view"]["pack_inside_pts2render"] = round(tot["pts2render"][0] - tot["render"][0], 3)
