@@ -164,7 +164,7 @@ def test_forward_backward_parity(name, family, lists):
     # --- image
     solid, touched, bounds = fragile_bounds(o, dpix)
     err = np.abs(img - oimg).max(0)
-    parity_report("parity[%s-%s]" % (family, name), img, oimg, grads, o.backward(dpix), solid, touched, visible=vis, bounds=bounds)
+    parity_report("parity[%s-%s-%s]" % (family, lists, name), img, oimg, grads, o.backward(dpix), solid, touched, visible=vis, bounds=bounds)
     assert solid.mean() > 0.995
     assert err[solid].max() <= RGB_TOL, "max err %.3e" % err[solid].max()
     assert err.max() <= 2.0 / 255 + 1e-3          # a flipped branch changes a pixel by at most one ~1/255 contribution
@@ -577,7 +577,7 @@ def test_fuzz_odd_shapes_and_degenerate_clouds(cfg, family, lists):
         assert err[solid].max() <= RGB_TOL, "max err %.3e" % err[solid].max()
     assert err.max() <= 2.0 / 255 + 1e-3
     og = o.backward(dpix)
-    parity_report("fuzz[%s-%dx%d_P%d]" % (family, W, H, P), img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
+    parity_report("fuzz[%s-%s-%dx%d_P%d]" % (family, lists, W, H, P), img, oimg, grads, og, solid, touched, visible=oradii > 0, bounds=bounds)
     assert_grad_parity(grads, og, touched, oradii > 0, bounds=bounds)
 
 

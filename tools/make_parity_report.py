@@ -3,8 +3,9 @@ Usage: python tools/make_parity_report.py [tag]"""
 import json, os, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 rows = [json.loads(l) for l in open(os.path.join(root, "gpurun_out", "parity_report.jsonl")) if l.strip()]
+rows = list({r["test"]: r for r in rows}.values())  # (a test that ran twice -- a re-run of part of the suite -- counts once: its last run)
 L = ["# Parity report of the GPU suite (`python -m pytest tests -m gpu`, MI355X): HIP path vs the fp32 C oracle on the same inputs.",
      "# Source: gpurun_out/parity_report.jsonl (tests/conftest.py::parity_report), formatted by tools/make_parity_report.py.",
      "# fragile = pixels within 1e-5 (relative) of an alpha / transmittance threshold in the oracle, or holding a pair whose exponent is within 1e-6 of upstream's",
@@ -12,9 +13,9 @@ L = ["# Parity report of the GPU suite (`python -m pytest tests -m gpu`, MI355X)
      "# (alpha >= 1/255 there, inside their tile rect, in front of a clear stop: oracle/gsr_oracle.c flip_bound) -- round 5; until round 4 it was every Gaussian whose radius + 1",
      "# bounding square held one.  strict set = visible Gaussians that are not touched: every one of them must be within 1e-3 in all gradient tensors.  A TOUCHED Gaussian may",
      "# exceed 1e-3 only by what a flipped branch decision at its fragile pixels can explain: |error| <= tolerance + 2 x flip bound, element by element (tests/conftest.py::",
-     "# assert_grad_parity); column 'touched: err / budget' is the worst such ratio (must be <= 1; full-size configs allow 2 per million up to 3).  GLOBAL: over ALL Gaussians fewer than",
+     "# assert_grad_parity); column 'touched: err / budget' is the worst such ratio (must be <= 1; full-size configs allow 2 per million up to 3; round 6: where a test excuses a handful, each stays below 3 and the 1e-4-band ratio in the notes is below 1 with nothing excused).  GLOBAL: over ALL Gaussians fewer than",
      "# 2e-3 (full-size configs: 1e-4) may be off by more than 1e-3.  Gradient columns: largest normalised error |a - ref| / (|ref| + 1e-3 max|ref|) over the untouched / the touched",
-     "# Gaussians (max over the tensors).  'config2' / 'config5' / 'config2_hr' / 'config2_colour_background' are the full-size BASELINE configs.", "",
+     "# Gaussians (max over the tensors).  'config2' / 'config5' / 'config2_hr' / 'config2_colour_background' are the full-size BASELINE configs.  Names carry the compositing family and, where a test runs both, the list form (direct / scanned).", "",
      "| test | pixels | fragile px | RGB max err (solid px) | px over 1e-4 | Gaussians | visible | touched | strict-set fraction | grad max err (untouched) | grad max err (touched) | touched: err / budget | over 1e-3 (all) | over 1e-3 (untouched) | notes |",
      "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for r in rows:
@@ -36,6 +37,9 @@ for r in rows:
         notes.append("%d pixels hold a pair with power == 0 exactly (compared, not excluded)" % r["pixels_flagged_by_power_band"])
     if r.get("longest_list") is not None:
         notes.append("longest bin list %d" % r["longest_list"])
+    if r.get("worst_err_over_budget_with_1e4_band") is not None:
+        notes.append("with the 1e-4 band (accumulated rounding of T after lists a thousand deep): worst err / budget %.3f over %d touched Gaussians, none excused" % (
+            r["worst_err_over_budget_with_1e4_band"], r["touched_with_1e4_band"]))
     sf = r.get("strict_set_fraction")
     L.append("| %s | %d | %d | %.2e | %d | %d | %s | %d | %s | %.2e | %.2e | %s | %d | %d | %s |" % (
         r["test"], r["pixels"], r["fragile_pixels"], r.get("rgb_max_err_solid", r["rgb_max_err"]), r["pixels_over_tol"], r["gaussians"],

@@ -2,7 +2,7 @@
 """One source for the numbers README.md quotes: a bench.py JSON line (the driver's BENCH_rNN.json `parsed` record, or a file holding the line) +
 profiles/<tag>_kernel_stats_one_view.md -> profiles/<tag>_numbers.md, and (with --readme) the block between the NUMBERS markers of README.md.
 
-    python tools/make_readme_numbers.py gpurun_out/r05_final/bench.json r05 [--readme]
+    python tools/make_readme_numbers.py gpurun_out/r06_final/bench.json r06 [--readme]
 """
 import json
 import os
@@ -32,10 +32,18 @@ def main():
              d["value"], d["ms_per_step"], d["ms_per_step_iqr"][0], d["ms_per_step_iqr"][1]),
          "| the same step through a C-ABI session (caller-owned buffers), one view at a time | %.0f views/s | %.4f |" % (sess["single_view_in_flight_views_per_s"], 1e3 / sess["single_view_in_flight_views_per_s"]),
          "| C-ABI sessions, %d independent views in flight on %d HIP streams | %.0f views/s | %.4f |" % (sess["views_in_flight"], sess["views_in_flight"], sess["views_in_flight_views_per_s"], sess["views_in_flight_ms_per_step"])]
-    if d.get("plugin_api_unpinned_views_per_s"):
+    L[4] = L[4].replace("exact capacity check): `value`", "exact capacity check, compiled host path, process NOT pinned): `value`")
+    if d.get("plugin_api_pinned_views_per_s"):
         aff = d.get("cpu_affinity")
-        L.insert(len(L) - 2, "| `value`'s process is pinned to %s CPUs of one L3 domain next to the GPU (`dist.pin_near_gpu`); the same step with every thread back on all CPUs, this box, this run | %.0f views/s | %.4f |" % (
-            aff.get("rank0_cpus") if isinstance(aff, dict) else "?", d["plugin_api_unpinned_views_per_s"], 1e3 / d["plugin_api_unpinned_views_per_s"]))
+        L.insert(len(L) - 2, "| the same step with the process pinned to %s CPUs of one L3 domain next to the GPU (`dist.pin_near_gpu`), this box, this run | %.0f views/s | %.4f |" % (
+            aff.get("rank0_cpus") if isinstance(aff, dict) else "?", d["plugin_api_pinned_views_per_s"], 1e3 / d["plugin_api_pinned_views_per_s"]))
+    if d.get("plugin_api_python_host_path_views_per_s"):
+        L.insert(len(L) - 2, "| the same step through the Python host path (`GPSGS_FAST=0`: what rounds 1-5 measured), same pinning state as the line above | %.0f views/s | %.4f |" % (
+            d["plugin_api_python_host_path_views_per_s"], 1e3 / d["plugin_api_python_host_path_views_per_s"]))
+    cold = d.get("single_view_cold") or {}
+    if cold.get("ms_cold"):
+        L.append("| C-ABI session step with a 1 GiB device fill between steps (COLD: workspace and inputs evicted from the Infinity Cache) / without the fill, same event bracket | %.0f / %.0f views/s | %.4f / %.4f |" % (
+            cold["single_view_cold_views_per_s"], cold["single_view_warm_same_method_views_per_s"], cold["ms_cold"], cold["ms_warm"]))
     if d.get("forward_only_views_per_s"):
         L.append("| forward only (plugin API, no_grad); `GPSGS_CHECK=deferred` forward + backward | %.0f; %.0f views/s | %.4f; %.4f |" % (
             d["forward_only_views_per_s"], d["deferred_check_views_per_s"]["fwd_bwd"], 1e3 / d["forward_only_views_per_s"], 1e3 / d["deferred_check_views_per_s"]["fwd_bwd"]))
@@ -67,11 +75,36 @@ def main():
     cs = d.get("cpu_taichi_splat_port") or {}
     if cs.get("value"):
         L.append("| CPU port of the reference's Taichi point splat (1 core; forward z-buffer splat only) | %.1f views/s | %.1f |" % (cs["value"], 1e3 / cs["value"]))
-    L += ["", "Per kernel, one view at a time (`stages`: hipEvent brackets, each ~1-3 µs above the rocprofv3 duration of `profiles/%s_kernel_stats_one_view.md`); bytes per launch:" % tag, "",
-          "| kernel | µs | algorithmic MB | counter MB (2 x FETCH + WRITE) | ratio | counter TB/s |", "|---|---|---|---|---|---|"]
+    L += ["", "Per kernel, one view at a time (`stages`: hipEvent brackets, each ~1-3 µs above the rocprofv3 duration of `profiles/%s_kernel_stats_one_view.md`); bytes per launch; "
+          "`hbm frac` from the counter bytes where known; VALU issue = wave64 VALU instructions x 4 cycles / (1,024 SIMDs x measured clock x t):" % tag, "",
+          "| kernel | µs | algorithmic MB | counter MB (2 x FETCH + WRITE) | ratio | hbm frac | VALU issue | bound |", "|---|---|---|---|---|---|---|---|"]
     for k, v in st.items():
-        L.append("| %s | %.1f | %.1f | %s | %s | %s |" % (k, v["avg_us"], v["algorithmic_bytes"] / 1e6, ("%.1f" % (v["counter_bytes"] / 1e6)) if "counter_bytes" in v else "",
-                                                       v.get("traffic_ratio", ""), ("%.2f" % (v["counter_gbs"] / 1e3)) if "counter_gbs" in v else ""))
+        L.append("| %s | %.1f | %.1f | %s | %s | %s | %s | %s |" % (k, v["avg_us"], v["algorithmic_bytes"] / 1e6, ("%.1f" % (v["counter_bytes"] / 1e6)) if "counter_bytes" in v else "",
+                                                                   v.get("traffic_ratio", ""), v.get("hbm_frac", ""), v.get("valu_issue_frac", ""), v.get("bound", "")))
+    nb = d.get("neighbours") or {}
+    if nb and "error" not in nb:
+        L += ["", "Neighbouring kernels (SURVEY section 8f rows f1-f4) at BASELINE config 4's sizes: GPU time (calls queued behind a spin kernel, one event bracket), algorithmic bytes, HBM fraction:", "",
+              "| op | kernels | forward µs | MB | hbm frac | backward µs | MB | hbm frac |", "|---|---|---|---|---|---|---|---|"]
+        for k, v in nb.items():
+            f, b = v.get("forward") or {}, v.get("backward") or {}
+            L.append("| %s | %s | %s | %s | %s | %s | %s | %s |" % (k, v.get("kernels", ""), f.get("us", ""), ("%.0f" % (f["algorithmic_bytes"] / 1e6)) if f else "", f.get("hbm_frac", ""),
+                                                                   b.get("us", ""), ("%.0f" % (b["algorithmic_bytes"] / 1e6)) if b else "", b.get("hbm_frac", "")))
+    rg = None
+    for name, c in (d.get("configs") or {}).items():
+        if "regime" in name and c.get("stages_one_view_in_flight"):
+            rg = c
+    if rg:
+        L += ["", "Untrained-heads regime (P = %d at %s, R = %d, scanned lists), per kernel, one view at a time:" % (rg["P"], rg["render"], rg["R"]), "",
+              "| kernel | µs | algorithmic MB | counter MB | hbm frac | VALU issue | bound |", "|---|---|---|---|---|---|---|"]
+        for k, v in rg["stages_one_view_in_flight"].items():
+            L.append("| %s | %.1f | %.1f | %s | %s | %s | %s |" % (k, v["avg_us"], v["algorithmic_bytes"] / 1e6, ("%.1f" % (v["counter_bytes"] / 1e6)) if "counter_bytes" in v else "",
+                                                                  v.get("hbm_frac", ""), v.get("valu_issue_frac", ""), v.get("bound", "")))
+        s2t = rg.get("stages_stage2_gradient_set") or {}
+        if s2t:
+            L.append("")
+            L.append("The two backward kernels with the gradient set stage 2 differentiates (no dL/dcolour: one-sector records that carry dL/dopacity): " +
+                     ", ".join("%s %.1f µs" % (k, v["avg_us"]) for k, v in s2t.items()) + "; forward + backward %s views/s one view at a time." % (
+                         (rg.get("fwd_bwd_stage2_gradient_set") or {}).get("one_view_in_flight", {}).get("views_per_s", "?")))
     L += ["", "Roofline of the dominant kernel (`%s`, %.1f µs exclusive, median block of %s launches): SURVEY §8(d) bytes %.1f MB -> %.0f GB/s = **%.3f of the 8 TB/s HBM peak**; with the implementation's own 8x8-bin instance count %.3f; "
           "by the counters %s GB/s (traffic ratio %s); VALU issue fraction %s at a measured %.0f MHz." % (
               rf["kernel"], rf["avg_launch_us"], rf.get("launches_averaged"), rf["algorithmic_bytes_per_launch"] / 1e6, rf["achieved"], rf["frac"], rf["frac_with_bin_8x8_instances"],

@@ -3,7 +3,7 @@
 #   trace   rocprofv3 --kernel-trace --stats: the default bench command (several views in flight in its session region) and
 #           --inflight 1 --headline-only (every launch has the chip to itself: the exclusive durations)
 #   pmc     --pmc SQ_* (instructions, wave / wait cycles), FETCH_SIZE, WRITE_SIZE, TCP->TCC requests on the ONE-VIEW-IN-FLIGHT command
-#   regime  FETCH_SIZE / WRITE_SIZE / kernel trace of the untrained-heads regime (bench.py's config3_regime leg: P = 550,000, 2048^2, scales at their clamp)
+#   regime  FETCH_SIZE / WRITE_SIZE / SQ instruction counts / kernel trace of the untrained-heads regime (bench.py's config3_regime leg: P = 550,000, 2048^2, scales at their clamp)
 # tools/make_profiles.py then writes <tag>_kernel_stats.md, <tag>_kernel_stats_one_view.md, <tag>_pmc_summary.md, pmc_traffic.json,
 # <tag>_regime_pmc_summary.md and pmc_traffic_regime.json (each with the workload it was measured on) into gpurun_out/prof_<tag>/.
 TAG=${1:-r06}
@@ -26,5 +26,6 @@ timeout 400 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_s
 timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $OUT/regime_trace -o t -- $REG > $OUT/regime_trace.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KRE" -f csv -d $OUT/regime_pmc_fetch -o p -- $REG > $OUT/regime_pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KRE" -f csv -d $OUT/regime_pmc_write -o p -- $REG > $OUT/regime_pmc_write.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-include-regex "$KRE" -f csv -d $OUT/regime_pmc_sq -o p -- $REG > $OUT/regime_pmc_sq.log 2>&1
 cd $ROOT
 python tools/make_profiles.py $OUT $TAG
