@@ -146,3 +146,44 @@ def test_staged_reference_build_is_bytecode_only_and_importable(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
     with open(os.path.join(ROOT, ".gitignore")) as f:
         assert "oracle/_ref/" in f.read().split()
+
+
+def test_list_form_policy_hysteresis_and_the_compiled_host_path_declines_what_it_does_not_take(monkeypatch):
+    """CPU: (a) rasterizer._note_longest -- one bin list beyond 768 entries puts a device on scanned lists (and the large-list sorts), eight views in a
+    row below 512 bring direct lists back, anything in between resets the streak; GPSGS_LISTS overrides.  (b) lib/_gpsgs_fast.so loads without a GPU,
+    reports the library's ABI version, and rasterize() returns None -- "not mine, take the Python path" -- for CPU tensors instead of touching them."""
+    import torch
+    from gps_gaussian_amd import rasterizer as RZ
+    st = dict(ratio=4.0, floor=1 << 16, pending=[])
+    monkeypatch.delenv("GPSGS_LISTS", raising=False)
+    assert RZ._bin_capacity(st, 1024, 1024) == RZ._DIRECT_CAP and RZ._bin_capacity(st, 4096, 2104) == 0   # (more than 65,536 bins: scanned)
+    RZ._note_longest(st, 700)
+    assert not st.get("big_bins", False)
+    RZ._note_longest(st, 769)
+    assert st["big_bins"] is True and RZ._bin_capacity(st, 1024, 1024) == 0
+    for k in range(7):
+        RZ._note_longest(st, 300)
+    assert st["big_bins"] is True
+    RZ._note_longest(st, 600)          # neither long nor short: the streak starts over
+    for k in range(7):
+        RZ._note_longest(st, 300)
+    assert st["big_bins"] is True
+    RZ._note_longest(st, 512)
+    assert st["big_bins"] is False and RZ._bin_capacity(st, 1024, 1024) == RZ._DIRECT_CAP
+    monkeypatch.setenv("GPSGS_LISTS", "scanned")
+    assert RZ._bin_capacity(st, 1024, 1024) == 0
+    monkeypatch.setenv("GPSGS_LISTS", "direct")
+    RZ._note_longest(st, 5000)
+    assert st["big_bins"] is True and RZ._bin_capacity(st, 1024, 1024) == RZ._DIRECT_CAP   # forced: the repair run of a too-long list still takes scanned lists
+    monkeypatch.setenv("GPSGS_LISTS", "nonsense")
+    with pytest.raises(ValueError):
+        RZ._bin_capacity(st, 1024, 1024)
+    monkeypatch.delenv("GPSGS_LISTS")
+    monkeypatch.setenv("GPSGS_FAST", "0")
+    assert RZ._fast_module() is False
+    monkeypatch.setenv("GPSGS_FAST", "1")
+    F = RZ._fast_module()
+    assert F and F.abi_version() == _capi.lib().gpsgs_abi_version() and F.slots_in_flight(0) == 0
+    z = torch.zeros
+    assert F.rasterize(z(4, 3), z(4, 3), z(4, 3), z(4, 1), z(4, 3), z(4, 4), z(3), z(16), z(16), 8, 8, 1.0, 1.0, 1.0, 100, 0, 0, 0) is None
+    assert len(F.last_header()) == 7
