@@ -54,6 +54,8 @@ def main(d, tag):
             if key.startswith("sort") and key != "sort":  # the multi-wave / large-list sort launches belong to the sort stage
                 if "sort" in out_:
                     out_["sort"]["hbm_bytes_per_launch"] += e["hbm_bytes_per_launch"]
+                    if "valu_wave_instructions_per_launch" in e:
+                        out_["sort"]["valu_wave_instructions_per_launch"] = out_["sort"].get("valu_wave_instructions_per_launch", 0.0) + e["valu_wave_instructions_per_launch"]
                     out_["sort"]["kernel"] += " + " + k0
                     continue
                 key = "sort"
