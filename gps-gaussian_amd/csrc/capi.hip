@@ -206,9 +206,9 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     float *final_T = reinterpret_cast<float *>(at(workspace, L.final_T));
     uint32_t *n_contrib = reinterpret_cast<uint32_t *>(at(workspace, L.n_contrib));
 
-    // header + scan partials (their ready flags) + bin_count + bin_count_fb are adjacent: one memset
+    // header + scan partials (their ready flags) + bin_count + bin_count_fb (+ bin_cursor with direct lists, where no scan initialises it) are adjacent
     {
-        const size_t zb = L.bin_offset - L.header;  // sections are 256-byte aligned: a whole number of 16-byte words
+        const size_t zb = (bin_cap ? L.bin_offset : L.bin_cursor) - L.header;  // sections are 256-byte aligned: a whole number of 16-byte words
         if ((zb & 15u) == 0 && (reinterpret_cast<uintptr_t>(hdr) & 15u) == 0) {
             const uint32_t n16 = (uint32_t)(zb >> 4);
             hipLaunchKernelGGL(k_zero16, dim3((n16 + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<uint4 *>(hdr), n16);
@@ -230,13 +230,7 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     q.row_range = row_range;
     q.shs = shs; q.campos = shs ? ext->campos : nullptr; q.cov3D_precomp = cov3D_precomp;
     q.sh_degree = shs ? ext->sh_degree : 0u; q.sh_coeffs = shs ? ext->sh_coeffs : 0u;
-    q.keys_direct = bin_cap ? keys : nullptr; q.bin_cap = bin_cap;
-    {
-        const int nt = ((L.bx + 7) / 8) * ((L.by + 7) / 8) * 64;
-        const size_t nscan = (size_t)((nt > L.NB ? nt : L.NB) + 63) / 64;
-        q.arrive = bin_cap ? reinterpret_cast<uint32_t *>(at(workspace, L.scan_part + gsr_direct_arrive_offset(nscan))) : nullptr;
-    }
-    const GsrBins bins = {bin_offset, bin_count, bin_cap};
+    const GsrBins bins = {bin_offset, bin_count, bin_count_fb, bin_cap};
     // a workspace that includes the backward tail gets the per-Gaussian slot prefix and cleared record flags from the forward
     const bool training = workspace_bytes >= L.total;
     q.goff = training ? reinterpret_cast<uint32_t *>(at(workspace, L.goff)) : nullptr;
@@ -252,12 +246,18 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     }
     if ((rc = check(s, flags)) != GPSGS_OK) return rc;
     if (bin_cap) {
-        // direct lists: k_preprocess has placed the keys; ONE more launch publishes the header (its first wave, also towards the host), sorts every bin's
-        // segment and, in its first workgroups, produces the work order and the slot prefix -- no scan in front of a scatter, no scatter
-        trace("sort+scan (direct lists)", P, width, height, (long long)instance_capacity, flags);
+        // direct lists: the scatter needs no offsets (slot = bin x capacity + recorded base + rank), its first workgroups publish the header (also towards the
+        // host) and do what is left of the scan (work order, slot prefix) beside the scattering ones
+        {
+            trace("scatter (direct lists)", P, width, height, (long long)instance_capacity, flags);
+            StageTimer t(flags, GSR_STAGE_SCATTER, s);
+            gsr_launch_scatter_direct(P, row_range, L.bx, L.by, L.NB, splats, binrec, wg_tab, bin_count, bin_count_fb, bin_cursor, bin_cap, keys, hdr, instance_capacity, q.gpart,
+                                      training ? reinterpret_cast<uint32_t *>(at(workspace, L.gprefix)) : nullptr, n_gblocks, wg_order, scan_part, order_hint, host_hdr, notify_seq, s);
+        }
+        if ((rc = check(s, flags)) != GPSGS_OK) return rc;
+        trace("sort (direct lists)", P, width, height, (long long)instance_capacity, flags);
         StageTimer t(flags, GSR_STAGE_SORT, s);
-        gsr_launch_sort_direct(L.NB, L.bx, L.by, bin_count, bin_cap, wg_order, scan_part, keys, point_list, instance_capacity, hdr, q.gpart, n_gblocks, host_hdr, notify_seq,
-                               order_hint, s);
+        gsr_launch_sort_direct(L.NB, bins, wg_order, keys, point_list, hdr, s);
     } else {
         {
             trace("scan", P, width, height, (long long)instance_capacity, flags);
@@ -359,14 +359,15 @@ extern "C" int gsr_backward_ex(int P, int width, int height, const float *means3
     if (workspace_bytes < L.total) return GPSGS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const GsrHeader *hdr = reinterpret_cast<const GsrHeader *>(at(workspace, L.header));
-    const GsrBins bins = {reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count)), bin_cap};
+    const GsrBins bins = {reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count)),
+                          reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count_fb)), bin_cap};
     const uint32_t *wg_order = reinterpret_cast<const uint32_t *>(at(workspace, L.wg_order));
     const GsrSplat *splats = reinterpret_cast<const GsrSplat *>(at(workspace, L.splats));
     const uint32_t *point_list = reinterpret_cast<const uint32_t *>(at(workspace, L.point_list));
     const float *final_T = reinterpret_cast<const float *>(at(workspace, L.final_T));
     const uint32_t *n_contrib = reinterpret_cast<const uint32_t *>(at(workspace, L.n_contrib));
     uint32_t *goff = reinterpret_cast<uint32_t *>(at(workspace, L.goff));
-    uint32_t *gscan_part = reinterpret_cast<uint32_t *>(at(workspace, L.gscan_part));
+    uint32_t *gscan_part = reinterpret_cast<uint32_t *>(at(workspace, L.gprefix));  // (the slot prefix per binning workgroup)
     uint8_t *inst_valid = reinterpret_cast<uint8_t *>(at(workspace, L.inst_valid));
     float *inst_dop = reinterpret_cast<float *>(at(workspace, L.inst_dop));
     GsrGradAcc *inst_grad = reinterpret_cast<GsrGradAcc *>(at(workspace, L.inst_grad));
@@ -509,7 +510,8 @@ extern "C" int gsr_export_state(const void *workspace, int P, int width, int hei
     const GsrLayout L = gsr_layout(P, width, height, instance_capacity, bin_capacity);
     hipStream_t s = (hipStream_t)stream;
     const int n = P > L.NB ? P : L.NB;
-    const GsrBins bins = {reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count)), bin_capacity};
+    const GsrBins bins = {reinterpret_cast<const uint32_t *>(at(workspace, L.bin_offset)), reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count)),
+                          reinterpret_cast<const uint32_t *>(at(workspace, L.bin_count_fb)), bin_capacity};
     if (n > 0)
         hipLaunchKernelGGL(k_export, dim3((n + 255) / 256), dim3(256), 0, s, P, L.NB, reinterpret_cast<const GsrSplat *>(at(workspace, L.splats)), bins, depth, xy,
                            conic_opacity, rect, tile_ranges);

@@ -257,17 +257,198 @@ __global__ __launch_bounds__(SB) void k_scan_b(const uint32_t *__restrict__ bin_
 constexpr int SC_PER = 2;                                // Gaussians per thread: a workgroup owns the Gaussians of ONE k_preprocess workgroup (its recorded table)
 constexpr int SC_THREADS = GSR_BIN_THREADS / SC_PER;     // threads of a scatter workgroup
 
+// ---- DIRECT lists (GsrBins::cap > 0; round 6) ----------------------------------------------------------------------------------------------------------
+// With a fixed-capacity segment per bin nothing downstream needs the exclusive scan of the counts any more, and the scatter needs nothing but the
+// counters k_preprocess left.  What is left of k_scan_b rides in the SCATTER launch, in workgroups in front of the scattering ones:
+//   - the totals (R, longest list, gradient slots, overflow) and the header, also towards the host: scatter_totals_block;
+//   - the work order of the compositing waves and the slot prefix of the gradient records: scan_wave_direct, one wave per 64 indices of the patch
+//     order.  The waves exchange their partials as one self-validating 64-bit word each, like k_scan_b's blocks (no fences); the scattering
+//     workgroups never wait for anything, so the polling scan waves cannot deadlock whatever the dispatch order (<= 1,024 of them).
+// The forward chain is then k_preprocess (count) -> k_scatter<true> -> k_sort_wave -> compositing: the ~10 us latency chain of the scan runs beside the
+// scatter instead of in front of it, and the scatter gathers no offsets.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+__device__ __forceinline__ unsigned long long poll_word(unsigned long long *w) {
+    unsigned long long v;
+    while (((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull) __builtin_amdgcn_s_sleep(1);
+    return v;
+}
+
+
+__device__ __forceinline__ void scan_wave_direct(int blk, int nscan, int lane, int bx, int by, const uint32_t *__restrict__ bin_count, const uint32_t *__restrict__ bin_count_fb,
+                                                 uint32_t *__restrict__ wg_order, unsigned long long *__restrict__ part /* 1 word per scan wave */, GsrHeader *__restrict__ hdr,
+                                                 const uint32_t *__restrict__ gpart, uint32_t *__restrict__ gprefix, int n_gblocks, uint32_t hint) {
+    const int b = blk * 64 + lane;
+    const int wb = gsr_tiled_bin((uint32_t)b, bx, by);
+    const uint32_t wc = wb >= 0 ? bin_count[wb] + bin_count_fb[wb] : 0u;
+    const int cls = gsr_work_class(wb, wc, hint);
+    const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+    // the slot prefix of the gradient records (training): the exclusive prefix (gprefix) of the per-workgroup slot counts k_preprocess left (gpart).  Scan wave
+    // `blk` owns workgroups [blk * gper, (blk + 1) * gper) (gper a multiple of 64; 64 up to 4 M Gaussians at 1024^2) and publishes their sum with its
+    // class counts.  
+    const int gper = gpart ? (((n_gblocks + nscan - 1) / nscan + 63) & ~63) : 0;
+    const int g0 = blk * gper, g1 = min(n_gblocks, g0 + gper);
+    uint32_t gv0 = 0u, gsum = 0u;
+    if (g0 < g1) {
+        gv0 = g0 + lane < g1 ? gpart[g0 + lane] : 0u;
+        gsum = gv0;
+        for (int k = g0 + 64 + lane; k < g1; k += 64) gsum += gpart[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) gsum += (uint32_t)__shfl_xor((int)gsum, d, 64);
+    }
+    if (lane == 0) {  // class counts <= 64: 7 bits each; the slot sum: 32 bits; + the ready bit: one self-validating word
+        const unsigned long long A = (unsigned long long)__popcll(m0) | ((unsigned long long)__popcll(m1) << 7) | ((unsigned long long)__popcll(m2) << 14) |
+                                     ((unsigned long long)__popcll(m3) << 21) | ((unsigned long long)gsum << 28) | (1ull << 63);
+        __hip_atomic_store(part + blk, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every scan wave needs the class totals of all of them and the prefix of those in front of it
+    uint32_t t[4] = {0u, 0u, 0u, 0u}, pre[4] = {0u, 0u, 0u, 0u}, gpre = 0u;
+    for (int i0 = 0; i0 < nscan; i0 += 256) {  // four words per lane requested together (one round trip for the 256 waves of a 1024^2 view), then polled
+        unsigned long long A[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u + lane;
+            A[u] = i < nscan ? __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull << 63;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u + lane;
+            if ((A[u] >> 63) == 0ull) A[u] = poll_word(part + i);
+            const uint32_t n0 = (uint32_t)A[u] & 0x7fu, n1 = (uint32_t)(A[u] >> 7) & 0x7fu, n2 = (uint32_t)(A[u] >> 14) & 0x7fu, n3 = (uint32_t)(A[u] >> 21) & 0x7fu;
+            t[0] += n0; t[1] += n1; t[2] += n2; t[3] += n3;
+            if (i < blk) { pre[0] += n0; pre[1] += n1; pre[2] += n2; pre[3] += n3; gpre += (uint32_t)(A[u] >> 28); }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            t[k] += (uint32_t)__shfl_xor((int)t[k], d, 64);
+            pre[k] += (uint32_t)__shfl_xor((int)pre[k], d, 64);
+        }
+        gpre += (uint32_t)__shfl_xor((int)gpre, d, 64);
+    }
+    if (g0 < g1) {
+        uint32_t carry = gpre;
+        for (int base = g0; base < g1; base += 64) {
+            const int k = base + lane;
+            const uint32_t v = base == g0 ? gv0 : (k < g1 ? gpart[k] : 0u);
+            const uint32_t x = wave_incl_scan(v, lane);
+            if (k < g1) gprefix[k] = carry + x - v;
+            carry += (uint32_t)__shfl((int)x, 63, 64);
+        }
+    }
+    const uint32_t tot_busy = t[0] + t[1] + t[2];
+    if (blk == 0 && lane == 0) hdr->num_busy_wgs = tot_busy;
+    // work order: the classes in order (longest lists first, idle bins last), patch order inside a class
+    if (wb >= 0) {
+        const unsigned long long mine = cls == 0 ? m0 : cls == 1 ? m1 : cls == 2 ? m2 : m3;
+        const uint32_t r = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+        const uint32_t pos = cls == 0 ? pre[0] + r : cls == 1 ? t[0] + pre[1] + r : cls == 2 ? t[0] + t[1] + pre[2] + r : tot_busy + pre[3] + r;
+        wg_order[pos] = (uint32_t)wb;
+    }
+}
+
+// DIRECT lists (GsrBins::cap > 0): the first SC_TOTALS workgroups of the launch do not scatter -- they add up the view from the counters k_preprocess
+// left (R = sum of count + count_fb, the longest list, the gradient slots from the per-workgroup slot totals), merge their partial sums with three
+// atomics each, and the last of them to finish publishes the header, also to the host: the early capacity notification leaves a few us into this
+// launch, before a single key is sorted.  (Rejected on the way, docs/HISTORY.md round 6: the scatter pass INSIDE k_preprocess -- 17 us there against 12.6 us as
+// its own kernel, the fused kernel is latency-bound -- and the totals from k_preprocess' last workgroup to arrive: +9 to +17 us of tail.)
+constexpr uint32_t SC_TOTALS = 32;  // (512 bins each at 1024^2: two loads in flight per thread, then 4 atomics per block)
+struct ScDirect {
+    const uint32_t *bin_count, *bin_count_fb, *gpart;
+    uint32_t *gprefix, *wg_order;
+    unsigned long long *part;
+    GsrHeader *hdr_w;
+    uint32_t *host_hdr;
+    int64_t slot_cap;
+    uint32_t bin_cap, host_seq, hint;
+    int NB, n_gblocks, by, nscan_wgs /* scan waves / 4 */;
+};
+
+__device__ __forceinline__ void scatter_totals_block(const ScDirect &d, uint32_t blk) {
+    __shared__ unsigned long long t_sum[SC_THREADS / 64];
+    __shared__ uint32_t t_max[SC_THREADS / 64], t_slots[SC_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (d.NB + (int)SC_TOTALS - 1) / (int)SC_TOTALS, b0 = (int)blk * per, b1 = min(d.NB, b0 + per);
+    unsigned long long sum = 0ull;
+    uint32_t mx = 0u, slots = 0u;
+#pragma unroll 2
+    for (int b = b0 + tid; b < b1; b += SC_THREADS) {
+        const uint32_t c = d.bin_count[(size_t)b * GSR_CPAD] + d.bin_count_fb[(size_t)b * GSR_CPAD];
+        sum += c;
+        mx = c > mx ? c : mx;
+    }
+    if (d.gpart) {
+        const int gper = (d.n_gblocks + (int)SC_TOTALS - 1) / (int)SC_TOTALS, g0 = (int)blk * gper, g1 = min(d.n_gblocks, g0 + gper);
+        for (int k = g0 + tid; k < g1; k += SC_THREADS) slots += d.gpart[k];
+    }
+#pragma unroll
+    for (int s_ = 32; s_ >= 1; s_ >>= 1) {
+        sum += (unsigned long long)__shfl_xor((long long)sum, s_, 64);
+        slots += (uint32_t)__shfl_xor((int)slots, s_, 64);
+        const uint32_t y = (uint32_t)__shfl_xor((int)mx, s_, 64);
+        mx = y > mx ? y : mx;
+    }
+    if (lane == 0) { t_sum[wid] = sum; t_max[wid] = mx; t_slots[wid] = slots; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < SC_THREADS / 64; w++) { sum += t_sum[w]; slots += t_slots[w]; mx = t_max[w] > mx ? t_max[w] : mx; }
+    GsrHeader *h = d.hdr_w;
+    unsigned long long *acc_sum = reinterpret_cast<unsigned long long *>(&h->reserved[0]);  // (the header is zeroed with the counters; reserved[] is 8-byte aligned)
+    if (sum) atomicAdd(acc_sum, sum);
+    if (mx) atomicMax(&h->reserved[2], mx);
+    if (slots) atomicAdd(&h->reserved[3], slots);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... this block's shares are in before it takes its ticket
+    if (atomicAdd(&h->reserved[4], 1u) != SC_TOTALS - 1u) return;
+    // the last totals block: every share is in (each block waited for its atomics before its ticket); read them past the caches
+    const unsigned long long tsum = __hip_atomic_load(acc_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tmax = __hip_atomic_load(&h->reserved[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tot_slots = __hip_atomic_load(&h->reserved[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a list longer than the bins' capacity is reported like an overflow (max_tile_count > capacity tells the caller which): nothing is composited
+    const bool ovf_b = tmax > d.bin_cap || (int64_t)tot_slots > d.slot_cap || h->row_overflow != 0u;
+    h->num_rendered = tsum;
+    h->overflow = ovf_b ? 1u : 0u;
+    h->max_tile_count = tmax;
+    h->num_slots = tot_slots;
+    if (d.host_hdr) {  // as k_scan_b: write-through stores, acknowledged, then the sequence word the host polls
+        const uint32_t hv[7] = {(uint32_t)tsum, (uint32_t)(tsum >> 32), ovf_b ? 1u : 0u, tmax, 0u /* busy bins: known after the sort launch */, tot_slots, h->num_points};
+#pragma unroll
+        for (int k = 0; k < 7; k++) __hip_atomic_store(d.host_hdr + k, hv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_store(d.host_hdr + 7, d.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // (6 waves per SIMD: every workgroup of a 600 k-Gaussian view is resident at once)
+template <bool DIRECT>
 __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_scatter(int P, const uint32_t *__restrict__ row_range, int bx, const GsrSplat *__restrict__ splats, const uint4 *__restrict__ binrec,
                                                        const uint32_t *__restrict__ wg_tab, const uint32_t *__restrict__ bin_offset, uint32_t *__restrict__ bin_cursor,
-                                                       uint64_t *__restrict__ keys, const GsrHeader *__restrict__ hdr) {
+                                                       uint64_t *__restrict__ keys, const GsrHeader *__restrict__ hdr, ScDirect dd) {
     __shared__ uint32_t s_cnt[GSR_BLOCK_TAB], s_base[GSR_BLOCK_TAB];
     __shared__ int s_box[4];
+    if (DIRECT && blockIdx.x < SC_TOTALS) {  // (workgroup-uniform)
+        scatter_totals_block(dd, blockIdx.x);
+        return;
+    }
+    if (DIRECT && blockIdx.x < SC_TOTALS + (uint32_t)dd.nscan_wgs) {
+        scan_wave_direct((int)(blockIdx.x - SC_TOTALS) * (SC_THREADS / 64) + (int)(threadIdx.x >> 6), dd.nscan_wgs * (SC_THREADS / 64), (int)(threadIdx.x & 63), bx, dd.by, dd.bin_count,
+                         dd.bin_count_fb, dd.wg_order, dd.part, dd.hdr_w, dd.gpart, dd.gprefix, dd.n_gblocks, dd.hint);
+        return;
+    }
+    const uint32_t wg = DIRECT ? blockIdx.x - SC_TOTALS - (uint32_t)dd.nscan_wgs : blockIdx.x;  // the k_preprocess workgroup whose Gaussians this one scatters
     // The kernel is a chain of memory round trips (round-5 counters: two thirds of its wave cycles are spent waiting): every load that depends on
     // nothing but the launch is issued FIRST -- the Gaussians' records, the table header AND the table entries (unconditionally: entries beyond the
     // box are never used), the slot run -- and only then examined.  What is left behind them is one gather of bin_offset.
-    const int i0 = blockIdx.x * GSR_BIN_THREADS;
-    const uint32_t *tab = wg_tab + (size_t)blockIdx.x * GSR_WG_TAB_WORDS;
+    const int i0 = (int)wg * GSR_BIN_THREADS;
+    const uint32_t *tab = wg_tab + (size_t)wg * GSR_WG_TAB_WORDS;
     uint4 rec[SC_PER];
 #pragma unroll
     for (int u = 0; u < SC_PER; u++) {
@@ -280,7 +461,7 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
     for (int k = 0; k < TPT; k++) tent[k] = tab[4 + k * SC_THREADS + (int)threadIdx.x];
     const int tab_bx0 = (int)tab[0], tab_by0 = (int)tab[1], tab_bw = (int)tab[2], tab_bh = (int)tab[3];
-    if (hdr->overflow) return;
+    if (!DIRECT && hdr->overflow) return;  // (direct lists: the totals blocks of THIS launch decide that; the guards below keep every store inside its bin's segment)
     {
         uint32_t row0;
         gsr_view_rows(row_range, P, row0, P);  // with a row range P was only the capacity: records behind the view's last Gaussian were never written
@@ -295,7 +476,8 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         toff[k] = 0u;
         if (t < area && tent[k]) {
             const int ty = t / tab_bw, tx = t - ty * tab_bw;
-            toff[k] = bin_offset[(tab_by0 + ty) * bx + tab_bx0 + tx];
+            const int bin = (tab_by0 + ty) * bx + tab_bx0 + tx;
+            toff[k] = DIRECT ? (uint32_t)bin * dd.bin_cap : bin_offset[bin];  // direct lists: the bin's segment starts at bin x capacity -- nothing to gather
         }
     }
     uint32_t lo[SC_PER], hi[SC_PER], mask[SC_PER];
@@ -325,9 +507,14 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
         for (int u = 0; u < SC_PER; u++) {
             const uint64_t k64 = key[u];
-            auto res = [&](int bin, uint32_t cnt) { return atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt); };
+            // scanned lists: the cursor starts behind the bin's recorded instances (k_scan_b); direct lists: it starts at 0 (zeroed with the counters) and
+            // the recorded count is added here
+            auto res = [&](int bin, uint32_t cnt) {
+                const uint32_t c = atomicAdd(&bin_cursor[(size_t)bin * GSR_CPAD], cnt);
+                return DIRECT ? (uint32_t)bin * dd.bin_cap + dd.bin_count[(size_t)bin * GSR_CPAD] + c : c;
+            };
             gsr_block_bin<true, SC_THREADS>(s_cnt, s_base, s_box, lo[u], hi[u], bx, gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]), res, res,
-                                            [&](uint32_t pos, uint32_t, uint32_t) { keys[pos] = k64; });
+                                            [&](uint32_t pos, uint32_t, uint32_t bin) { if (!DIRECT || pos - bin * dd.bin_cap < dd.bin_cap) keys[pos] = k64; });
         }
         return;
     }
@@ -342,13 +529,15 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         const uint32_t e = tab[4 + t];
         const int ty = t / tab_bw, tx = t - ty * tab_bw;
         s_cnt[t] = 0u;
-        s_base[t] = (e ? bin_offset[(tab_by0 + ty) * bx + tab_bx0 + tx] : 0u) + e - 1u;
+        const int bin_ = (tab_by0 + ty) * bx + tab_bx0 + tx;
+        s_base[t] = (e ? (DIRECT ? (uint32_t)bin_ * dd.bin_cap : bin_offset[bin_]) : 0u) + e - 1u;
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SC_PER; u++) {
         const uint64_t k64 = key[u];
-        gsr_block_emit_one(s_cnt, s_base, tab_bx0, tab_by0, tab_bw, bx, lo[u], hi[u], gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]), [&](uint32_t pos, uint32_t, uint32_t) { keys[pos] = k64; });
+        gsr_block_emit_one(s_cnt, s_base, tab_bx0, tab_by0, tab_bw, bx, lo[u], hi[u], gsr_masked_hit(hit[u], mask[u], lo[u], hi[u]),
+                           [&](uint32_t pos, uint32_t, uint32_t bin) { if (!DIRECT || pos - bin * dd.bin_cap < dd.bin_cap) keys[pos] = k64; });  // (a list beyond the capacity: reported, not written)
     }
 }
 
@@ -701,152 +890,16 @@ __device__ __forceinline__ void sort_wave_list(const uint64_t *__restrict__ seg,
 }
 
 // lists of 1..1024 keys (the common case: a body bin holds ~450): ONE WAVE per bin, keys in registers.
-__global__ __launch_bounds__(64) void k_sort_wave(const uint32_t *__restrict__ bin_offset, const uint32_t *__restrict__ wg_order,
-                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+__global__ __launch_bounds__(64) void k_sort_wave(GsrBins bins, const uint32_t *__restrict__ wg_order, uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                   const GsrHeader *__restrict__ hdr) {
     const uint32_t bin = wg_order[blockIdx.x];  // busy bins first (requested together with the header: one round trip, not two)
     if (hdr->overflow || blockIdx.x >= hdr->num_busy_wgs) return;
-    const uint32_t off = bin_offset[bin], n = bin_offset[bin + 1] - off;
+    uint32_t off, end;
+    gsr_bin_range(bins, bin, off, end);
+    const uint32_t n = end - off;
     if (n == 0 || n > 1024u) return;
     __shared__ uint32_t ids[1024];
     sort_wave_list(keys + off, n, point_list + off, ids, (int)threadIdx.x);
-}
-
-// ---- DIRECT lists (GsrBins::cap > 0; round 6): the sort launch carries the scan ------------------------------------------------------------------------
-// With a fixed-capacity segment per bin nothing downstream needs the exclusive scan of the counts any more.  What is left of k_scan_b: the totals
-// (R, longest list, overflow) and the header, also towards the host -- k_preprocess' workgroups accumulate them in a few sharded counters as they go
-// and the FIRST wave of this launch publishes them, so the host learns them about as early as with scanned lists -- and the work order of the
-// compositing waves + the slot prefix of the gradient records.  Neither of the latter is needed by the sort, so they ride in the sort's launch: workgroups [0, nscan) (one wave each, 64 indices of the patch order
-// per wave) do the scan work -- they exchange their partials as self-validating 64-bit words like k_scan_b's blocks (no fences) -- while workgroups
-// nscan + b sort bin b.  The sorting waves never wait for anything, so the polling scan waves cannot deadlock whatever the dispatch order (<= 1,024
-// of them: GSR_DIRECT_MAX_BINS; they are the first workgroups of the grid and in practice all resident before the first sort wave).  The forward
-// chain is then k_preprocess (count + scatter) -> this launch -> compositing: three dependent launches instead of five (zero, preprocess, scan,
-// scatter, sort), and the 10 us latency chain of the scan overlaps the sort instead of preceding the scatter.
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    return x;
-}
-__device__ __forceinline__ unsigned long long poll_word(unsigned long long *w) {
-    unsigned long long v;
-    while (((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull) __builtin_amdgcn_s_sleep(1);
-    return v;
-}
-
-__global__ __launch_bounds__(64) void k_sort_direct(int nscan, int NB, int bx, int by, const uint32_t *__restrict__ bin_count, uint32_t bin_cap,
-                                                    uint32_t *__restrict__ wg_order, unsigned long long *__restrict__ part /* 1 word per scan workgroup */,
-                                                    const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
-                                                    GsrHeader *__restrict__ hdr, uint32_t *__restrict__ gpart, int n_gblocks, uint32_t hint,
-                                                    const uint32_t *__restrict__ shards, int64_t slot_cap, uint32_t *__restrict__ host_hdr, uint32_t host_seq) {
-    __shared__ uint32_t ids[1024];
-    const int lane = threadIdx.x;
-    if (blockIdx.x == 0) {
-        // the view's totals, first thing in the launch: k_preprocess' workgroups left {instances | slots << 32, longest list} in GSR_ARRIVE_SHARDS
-        // accumulators; they become the header -- and the host's early capacity notification, ~3 us behind the end of k_preprocess
-        unsigned long long acc = 0ull;
-        uint32_t mx = 0u;
-        if (lane < GSR_ARRIVE_SHARDS) {
-            acc = *reinterpret_cast<const unsigned long long *>(shards + 16 * lane);
-            mx = shards[16 * lane + 2];
-        }
-        uint32_t inst = (uint32_t)acc, slots = (uint32_t)(acc >> 32);
-        unsigned long long tsum = inst;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            tsum += (unsigned long long)__shfl_xor((long long)tsum, d, 64);
-            slots += (uint32_t)__shfl_xor((int)slots, d, 64);
-            const uint32_t y = (uint32_t)__shfl_xor((int)mx, d, 64);
-            mx = y > mx ? y : mx;
-        }
-        if (lane == 0) {
-            // a list longer than the bins' capacity is reported like an overflow (max_tile_count > capacity tells the caller which): nothing is composited
-            const bool ovf_b = mx > bin_cap || (int64_t)slots > slot_cap || hdr->row_overflow != 0u;
-            hdr->num_rendered = tsum;
-            hdr->overflow = ovf_b ? 1u : 0u;
-            hdr->max_tile_count = mx;
-            hdr->num_slots = slots;
-            if (host_hdr) {  // as k_scan_b: write-through stores, acknowledged, then the sequence word the host polls
-                const uint32_t hv[7] = {(uint32_t)tsum, (uint32_t)(tsum >> 32), ovf_b ? 1u : 0u, mx, 0u /* busy bins: known at the end of this launch */, slots, hdr->num_points};
-#pragma unroll
-                for (int k = 0; k < 7; k++) __hip_atomic_store(host_hdr + k, hv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __builtin_amdgcn_s_waitcnt(0);
-                __hip_atomic_store(host_hdr + 7, host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-    if ((int)blockIdx.x >= nscan) {  // ---- a sorting wave
-        const uint32_t bin = blockIdx.x - (uint32_t)nscan;
-        const uint32_t cnt = bin_count[bin];
-        const uint32_t n = cnt < bin_cap ? cnt : bin_cap;  // (a longer list is an overflow: the first wave of this launch reports it, nothing is composited)
-        if (n == 0u) return;
-        const size_t off = (size_t)bin * bin_cap;
-        sort_wave_list(keys + off, n, point_list + off, ids, lane);
-        return;
-    }
-    // ---- a scan wave: 64 indices of the patch order -> their places in the work order
-    const int blk = blockIdx.x;
-    const int b = blk * 64 + lane;
-    const int wb = gsr_tiled_bin((uint32_t)b, bx, by);
-    const uint32_t wc = wb >= 0 ? bin_count[wb] : 0u;
-    const int cls = gsr_work_class(wb, wc, hint);
-    const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
-    if (lane == 0) {  // class counts <= 64: 7 bits each, + the ready bit: one self-validating word
-        const unsigned long long A = (unsigned long long)__popcll(m0) | ((unsigned long long)__popcll(m1) << 7) | ((unsigned long long)__popcll(m2) << 14) |
-                                     ((unsigned long long)__popcll(m3) << 21) | (1ull << 63);
-        __hip_atomic_store(part + blk, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // the slot prefix of the gradient records (training): one scan wave (the second, when there is one) turns the per-block slot counts k_preprocess
-    // left into their exclusive prefix, in place
-    if (gpart && blk == (nscan > 1 ? 1 : 0)) {
-        uint32_t carry = 0u;
-        for (int base = 0; base < n_gblocks; base += 64 * 8) {
-            uint32_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {  // eight independent loads in flight, then eight wave scans
-                const int k = base + u * 64 + lane;
-                v[u] = k < n_gblocks ? gpart[k] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = base + u * 64 + lane;
-                const uint32_t x = wave_incl_scan(v[u], lane);
-                if (k < n_gblocks) gpart[k] = carry + x - v[u];
-                carry += (uint32_t)__shfl((int)x, 63, 64);
-            }
-        }
-    }
-    // every scan wave needs the class totals of all of them and the prefix of those in front of it
-    uint32_t t[4] = {0u, 0u, 0u, 0u}, pre[4] = {0u, 0u, 0u, 0u};
-    for (int i0 = 0; i0 < nscan; i0 += 64) {
-        const int i = i0 + lane;
-        if (i < nscan) {
-            const unsigned long long A = poll_word(part + i);
-            const uint32_t n0 = (uint32_t)A & 0x7fu, n1 = (uint32_t)(A >> 7) & 0x7fu, n2 = (uint32_t)(A >> 14) & 0x7fu, n3 = (uint32_t)(A >> 21) & 0x7fu;
-            t[0] += n0; t[1] += n1; t[2] += n2; t[3] += n3;
-            if (i < blk) { pre[0] += n0; pre[1] += n1; pre[2] += n2; pre[3] += n3; }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            t[k] += (uint32_t)__shfl_xor((int)t[k], d, 64);
-            pre[k] += (uint32_t)__shfl_xor((int)pre[k], d, 64);
-        }
-    }
-    const uint32_t tot_busy = t[0] + t[1] + t[2];
-    if (blk == 0 && lane == 0) hdr->num_busy_wgs = tot_busy;
-    // work order: the classes in order (longest lists first, idle bins last), patch order inside a class
-    if (wb >= 0) {
-        const unsigned long long mine = cls == 0 ? m0 : cls == 1 ? m1 : cls == 2 ? m2 : m3;
-        const uint32_t r = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
-        const uint32_t pos = cls == 0 ? pre[0] + r : cls == 1 ? t[0] + pre[1] + r : cls == 2 ? t[0] + t[1] + pre[2] + r : tot_busy + pre[3] + r;
-        wg_order[pos] = (uint32_t)wb;
-    }
 }
 
 // ---- lists of 1,025 .. 8,192 keys: 1 / 2 / 4 waves per list, 32 keys per lane in registers -------------------------------------------
@@ -1052,14 +1105,29 @@ void gsr_launch_scan(const uint32_t *bin_count, const uint32_t *bin_count_fb, ui
 void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_offset,
                         uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(SC_THREADS), 0, s, P, row_range, bx, splats, binrec, wg_tab, bin_offset, bin_cursor, keys,
-                       hdr);
+    hipLaunchKernelGGL(k_scatter<false>, dim3((P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(SC_THREADS), 0, s, P, row_range, bx, splats, binrec, wg_tab, bin_offset, bin_cursor, keys,
+                       hdr, ScDirect{});
+}
+
+void gsr_launch_scatter_direct(int P, const uint32_t *row_range, int bx, int by, int NB, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_count,
+                               const uint32_t *bin_count_fb, uint32_t *bin_cursor, uint32_t bin_cap, uint64_t *keys, GsrHeader *hdr, int64_t slot_cap, const uint32_t *gpart,
+                               uint32_t *gprefix, int n_gblocks, uint32_t *wg_order, uint4 *scan_part, uint32_t order_hint, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s) {
+    if (P <= 0) return;
+    const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB)
+    ScDirect d;
+    d.bin_count = bin_count; d.bin_count_fb = bin_count_fb; d.gpart = gpart; d.gprefix = gprefix; d.wg_order = wg_order;
+    d.part = reinterpret_cast<unsigned long long *>(scan_part);
+    d.hdr_w = hdr; d.host_hdr = host_hdr; d.slot_cap = slot_cap;
+    d.bin_cap = bin_cap; d.host_seq = host_seq; d.hint = order_hint; d.NB = NB; d.n_gblocks = n_gblocks; d.by = by;
+    d.nscan_wgs = ((NT > NB ? NT : NB) + SC_THREADS - 1) / SC_THREADS;
+    hipLaunchKernelGGL(k_scatter<true>, dim3(SC_TOTALS + d.nscan_wgs + (P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS), dim3(SC_THREADS), 0, s, P, row_range, bx, splats, binrec, wg_tab,
+                       nullptr, bin_cursor, keys, hdr, d);
 }
 
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s) {
     if (NB <= 0) return;
-    hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bin_offset, wg_order, keys, point_list, hdr);
+    hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, GsrBins{bin_offset, nullptr, nullptr, 0u}, wg_order, keys, point_list, hdr);
     if (no_large_sort) return;  // the scan has turned any list longer than 1024 into an overflow (nothing downstream runs)
     // 1,025 .. 8,192 keys: 1 / 2 / 4 waves per list, keys in registers (each launch returns at once when the view's longest list is below its class)
     // Grid of the one-wave class: MANY more workgroups than the chip holds at once, so that the hardware dispatcher deals the lists out dynamically
@@ -1077,13 +1145,7 @@ void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_orde
     hipLaunchKernelGGL(k_sort_large, dim3(NB < 1024 ? NB : 1024), dim3(1024), 0, s, NB, bin_offset, keys, point_list, hdr);
 }
 
-void gsr_launch_sort_direct(int NB, int bx, int by, const uint32_t *bin_count, uint32_t bin_cap, uint32_t *wg_order, uint4 *scan_part, uint64_t *keys,
-                            uint32_t *point_list, int64_t slot_cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq,
-                            uint32_t order_hint, hipStream_t s) {
+void gsr_launch_sort_direct(int NB, GsrBins bins, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list, const GsrHeader *hdr, hipStream_t s) {
     if (NB <= 0) return;
-    const int NT = ((bx + 7) / 8) * ((by + 7) / 8) * 64;  // indices of the patch order (>= NB)
-    const int nscan = ((NT > NB ? NT : NB) + 63) / 64;
-    const uint32_t *shards = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(scan_part) + gsr_direct_arrive_offset((size_t)nscan));
-    hipLaunchKernelGGL(k_sort_direct, dim3(nscan + NB), dim3(64), 0, s, nscan, NB, bx, by, bin_count, bin_cap, wg_order, reinterpret_cast<unsigned long long *>(scan_part), keys,
-                       point_list, hdr, gpart, n_gblocks, order_hint, shards, slot_cap, host_hdr, host_seq);
+    hipLaunchKernelGGL(k_sort_wave, dim3(NB), dim3(64), 0, s, bins, wg_order, keys, point_list, hdr);
 }

@@ -75,12 +75,12 @@ static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte
 
 // Per-bin list ranges as the kernels behind the binning see them.  Two forms (GsrViewExt.bin_capacity):
 //   scanned lists (cap == 0): bin b owns [offset[b], offset[b + 1]) of keys / point_list -- the exclusive scan of the counts (k_scan_b);
-//   DIRECT lists (cap > 0, round 6): bin b owns [b * cap, b * cap + count[b]) -- a fixed-capacity segment per bin, so that an instance's slot is known
-//     the moment k_preprocess' count atomic returns: the scatter pass runs inside k_preprocess, k_scatter and its tables disappear, and the scan (which
-//     still produces the work order and the header) leaves the critical path (it rides in the sort launch).  A view whose longest list exceeds cap is
-//     reported as an overflow (header.max_tile_count > cap) and the caller repeats it with scanned lists.
+//   DIRECT lists (cap > 0, round 6): bin b owns [b * cap, b * cap + count[b] + count_fb[b]) -- a fixed-capacity segment per bin, so that an instance's slot
+//     follows from the base k_preprocess' count atomic returned without any offsets: the scatter pass needs no scan in front of it, and what is left
+//     of the scan (work order, slot prefix) leaves the critical path (it rides in the sort launch).  A view whose longest list exceeds cap is reported
+//     as an overflow (header.max_tile_count > cap) and the caller repeats it with scanned lists.
 struct GsrBins {
-    const uint32_t *offset, *count;
+    const uint32_t *offset, *count, *count_fb;  // (direct lists: a bin's length is count + count_fb -- the recorded workgroups' instances + the unrecorded ones')
     uint32_t cap;
 };
 
@@ -89,7 +89,7 @@ struct GsrLayout {
     uint32_t bin_cap;  // 0: scanned lists; else the per-bin capacity of direct lists
     int64_t key_cap;   // entries of keys / point_list: the instance capacity, or NB * bin_cap
     size_t total_fwd;  // bytes a forward-only workspace needs
-    size_t goff, gscan_part, inst_valid, inst_dop, inst_grad, total;
+    size_t goff, gscan_part, gprefix, inst_valid, inst_dop, inst_grad, total;
     int gx, gy;   // 16x16 tile grid (upstream semantics)
     int bx, by;   // bin grid: bx = ceil(W/8) rounded up to a multiple of 4, by = ceil(H/8)
     int bx_real;  // ceil(W/8)
@@ -99,8 +99,6 @@ struct GsrLayout {
 };
 
 static inline size_t gsr_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
-#define GSR_ARRIVE_SHARDS 32
-static inline size_t gsr_direct_arrive_offset(size_t nscan) { return ((nscan + 1) * 8 + 127) & ~(size_t)127; }  // inside the scan_part section
 
 static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap, uint32_t bin_cap = 0u) {
     GsrLayout L;
@@ -123,19 +121,18 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap, uint32_t bi
     {   // two 64-bit words per scan block (+ padding); direct lists: two per scan WAVE of the sort launch (64 patch-order indices each) + one
         const size_t nt = (size_t)((L.bx + 7) / 8) * ((L.by + 7) / 8) * 64;
         const size_t nscan = ((nt > t ? nt : t) + 63) / 64;
-        // direct lists: one word per scan wave, then (128-byte aligned) the total accumulators of k_preprocess' workgroups, GSR_ARRIVE_SHARDS x 64 bytes
-        const size_t a = ((size_t)L.NSB + 1) * 32, b = bin_cap ? gsr_direct_arrive_offset(nscan) + GSR_ARRIVE_SHARDS * 64 : 0;
+        // direct lists: one word per scan wave of the scatter launch (whole workgroups of four)
+        const size_t a = ((size_t)L.NSB + 1) * 32, b = bin_cap ? (nscan + 8) * 8 : 0;
         L.scan_part = o;  o = gsr_align_up(o + (a > b ? a : b));
     }
     L.bin_count = o;  o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.bin_count_fb = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);  // instances counted by workgroups whose bins do not fit the LDS table (see gsr_block_bin)
+    L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);  // (inside the zeroed range: with direct lists the unrecorded workgroups' cursors start at 0)
     L.bin_offset = o; o = gsr_align_up(o + (t + 1) * 4);
-    L.bin_cursor = o; o = gsr_align_up(o + t * 4 * GSR_CPAD);
     L.wg_order = o;   o = gsr_align_up(o + (t / GSR_BINS_PER_WG + 1) * 4);
     L.splats = o;     o = gsr_align_up(o + p * sizeof(GsrSplat));
-    // (binrec / wg_tab carry the count pass' decisions to k_scatter: direct lists have no scatter pass)
-    L.binrec = o;     o = gsr_align_up(o + (bin_cap ? 1 : p) * 16);
-    L.wg_tab = o;     o = gsr_align_up(o + (bin_cap ? 1 : ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS)) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
+    L.binrec = o;     o = gsr_align_up(o + p * 16);
+    L.wg_tab = o;     o = gsr_align_up(o + ((p + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS) * (size_t)(4 + GSR_BLOCK_TAB) * 4);
     L.key_cap = bin_cap ? (int64_t)t * (int64_t)bin_cap : (int64_t)c;
     L.keys = o;       o = gsr_align_up(o + (size_t)L.key_cap * 8);
     L.point_list = o; o = gsr_align_up(o + (size_t)L.key_cap * 4);
@@ -144,6 +141,9 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap, uint32_t bi
     L.total_fwd = o;
     L.goff = o;       o = gsr_align_up(o + (p + 1) * 4);
     L.gscan_part = o; o = gsr_align_up(o + (p / GSR_BIN_THREADS + 2) * 4);
+    // direct lists: the prefix is written beside the counts, not over them (the totals workgroups of the scatter launch read the counts while its scan waves scan them)
+    L.gprefix = bin_cap ? o : L.gscan_part;
+    if (bin_cap) o = gsr_align_up(o + (p / GSR_BIN_THREADS + 2) * 4);
     L.inst_valid = o; o = gsr_align_up(o + c);
     L.inst_dop = o;   o = gsr_align_up(o + c * 4);
     L.inst_grad = o;  o = gsr_align_up(o + c * sizeof(GsrGradAcc));
@@ -154,7 +154,7 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap, uint32_t bi
 #if defined(__HIPCC__)
 __device__ __forceinline__ void gsr_bin_range(const GsrBins &b, uint32_t bin, uint32_t &r0, uint32_t &r1) {
     if (b.cap) {  // (kernel-argument uniform)
-        const uint32_t n = b.count[bin];
+        const uint32_t n = b.count[bin] + b.count_fb[bin];
         r0 = bin * b.cap;
         r1 = r0 + (n < b.cap ? n : b.cap);  // (a longer list is an overflow: nothing behind the scan runs; the clamp only keeps a debug read inside its segment)
     } else {
@@ -471,11 +471,6 @@ struct GsrFwdParams {
     const float *shs, *campos, *cov3D_precomp;  // [rows, sh_coeffs, 3], [3], [rows, 6]; NULL = not used
     uint32_t sh_degree, sh_coeffs;
     float fx, fy;  // focal lengths in pixels, W / (2 tanfovx): set by gsr_launch_preprocess (two IEEE divisions per THREAD of a VALU-bound kernel otherwise)
-    // direct lists (GsrBins::cap > 0): k_preprocess drops the keys into the bins' fixed-capacity segments itself and accumulates the view's totals
-    // (instances, slots, longest list) in `arrive`: GSR_ARRIVE_SHARDS accumulators {u64 instances | slots << 32, u32 longest}, 64 bytes apart, zeroed with the header
-    uint64_t *keys_direct;
-    uint32_t bin_cap;
-    uint32_t *arrive;
 };
 
 void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binrec, uint32_t *wg_tab, uint32_t *bin_count, uint32_t *bin_count_fb, GsrHeader *hdr,
@@ -486,15 +481,17 @@ void gsr_launch_scan(const uint32_t *bin_count, const uint32_t *bin_count_fb, ui
                      hipStream_t s);
 void gsr_launch_scatter(int P, const uint32_t *row_range, int bx, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_offset,
                         uint32_t *bin_cursor, uint64_t *keys, const GsrHeader *hdr, hipStream_t s);
+// direct lists: the same scatter pass with slot = bin * bin_cap + recorded base + rank (no offsets to gather).  Workgroups in front of the scattering ones
+// do what is left of the scan from the counters k_preprocess left: the totals -- R, longest list, gradient slots -- and the header, also to the host (early
+// capacity notification); the work order of the compositing waves; the slot prefix of the gradient records (gpart: counts in, gprefix: prefix out)
+void gsr_launch_scatter_direct(int P, const uint32_t *row_range, int bx, int by, int NB, const GsrSplat *splats, const uint4 *binrec, const uint32_t *wg_tab, const uint32_t *bin_count,
+                               const uint32_t *bin_count_fb, uint32_t *bin_cursor, uint32_t bin_cap, uint64_t *keys, GsrHeader *hdr, int64_t slot_cap, const uint32_t *gpart,
+                               uint32_t *gprefix, int n_gblocks, uint32_t *wg_order, uint4 *scan_part, uint32_t order_hint, uint32_t *host_hdr, uint32_t host_seq, hipStream_t s);
 void gsr_launch_sort(int NB, const uint32_t *bin_offset, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list,
                      const GsrHeader *hdr, bool no_large_sort, hipStream_t s);
-// direct lists: ONE launch sorts every bin's segment (one wave per bin, n <= bin_cap <= 1024) and, in its first workgroups, does what is left of
-// k_scan_b's work -- the work order of the compositing waves and the slot prefix of the gradient records (the totals and the header were published
-// by the last workgroup of k_preprocess)
-void gsr_launch_sort_direct(int NB, int bx, int by, const uint32_t *bin_count, uint32_t bin_cap, uint32_t *wg_order, uint4 *scan_part, uint64_t *keys,
-                            uint32_t *point_list, int64_t slot_cap, GsrHeader *hdr, uint32_t *gpart, int n_gblocks, uint32_t *host_hdr, uint32_t host_seq,
-                            uint32_t order_hint, hipStream_t s);
-#define GSR_DIRECT_MAX_BINS 65536  // direct lists: the scan workgroups of the sort launch poll each other's partials (all resident: <= 1,024 of them)
+// lists of <= 1,024 keys, either list form (direct lists hold nothing longer): one wave per busy bin
+void gsr_launch_sort_direct(int NB, GsrBins bins, const uint32_t *wg_order, uint64_t *keys, uint32_t *point_list, const GsrHeader *hdr, hipStream_t s);
+#define GSR_DIRECT_MAX_BINS 65536  // direct lists: the scan waves of the scatter launch poll each other's partials (all resident: <= 1,024 of them)
 #define GSR_DIRECT_MAX_CAP 1024    // ... and a bin's list is sorted by ONE wave (k_sort_wave's classes)
 void gsr_launch_composite_fwd(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                               const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr,

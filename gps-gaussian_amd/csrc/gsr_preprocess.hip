@@ -181,38 +181,11 @@ struct CountHit {
     }
 };
 
-// DIRECT lists: count pass and scatter pass run back to back in k_preprocess, so the predicate is evaluated by ONE object in both: a cell of a small
-// rect is tested once and remembered (tested / hit bit masks in registers); large rects re-derive their row intervals (or, ill-conditioned, their cells)
-// from the same numbers -- same code, same registers: the two passes cannot disagree.
-struct DirectHit {
-    GsrHit h;
-    GsrRowSpan rs;
-    uint32_t *hitm, *tested;
-    int x0, y0, w;
-    bool rows;
-    __device__ __forceinline__ void span(int y, int &xa, int &xb) const {
-        if (rows) gsr_row_cells(rs, y, xa, xb, xa, xb);
-    }
-    __device__ __forceinline__ bool operator()(int x, int y) const {
-        if (rows) return true;
-        const int k = (y - y0) * w + (x - x0);
-        if (k < 32 && ((*tested >> k) & 1u)) return (*hitm >> k) & 1u;
-        const bool hh = gsr_bin_hit(h, x, y);
-        if (k < 32) { *tested |= 1u << k; if (hh) *hitm |= 1u << k; }
-        return hh;
-    }
-};
-
 // APPEAR = false: the inputs the reference passes (precomputed colours, scale + rotation): the instantiation every measured configuration runs.
 // APPEAR = true: SH colours (q.shs) and / or precomputed 3D covariances (q.cov3D_precomp) -- its own instantiation, so that the common one carries
 // neither the branches nor the registers of these inputs.
-// DIRECT = true: direct lists (GsrBins::cap > 0): the keys go straight into the bins' fixed-capacity segments (q.keys_direct, q.bin_cap per bin) -- no
-// wg_tab / binrec, no k_scatter.
-#ifndef GSR_PRE_SGPRS
-#define GSR_PRE_SGPRS 80  // 512-thread workgroups are admitted 4 per CU up to 80 SGPRs, 3 beyond (the direct-list instantiation asked for 101)
-#endif
-template <bool APPEAR, bool DIRECT>
-__global__ __launch_bounds__(GSR_BIN_THREADS) __attribute__((amdgpu_num_sgpr(GSR_PRE_SGPRS))) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint4 *__restrict__ binrec,
+template <bool APPEAR>
+__global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, GsrSplat *__restrict__ splats, uint4 *__restrict__ binrec,
                                                                uint32_t *__restrict__ wg_tab, uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_count_fb,
                                                                GsrHeader *__restrict__ hdr) {
     const int i = blockIdx.x * GSR_BIN_THREADS + threadIdx.x;
@@ -236,10 +209,8 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) __attribute__((amdgpu_num_sgpr(GSR
             if (i < q.P) q.goff[i] = 0u;
             if (threadIdx.x == 0) q.gpart[blockIdx.x] = 0u;
         }
-        if (!DIRECT) {
-            if (i < q.P) binrec[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (threadIdx.x < 4) wg_tab[(size_t)blockIdx.x * GSR_WG_TAB_WORDS + threadIdx.x] = 0u;
-        }
+        if (i < q.P) binrec[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x < 4) wg_tab[(size_t)blockIdx.x * GSR_WG_TAB_WORDS + threadIdx.x] = 0u;
         return;
     }
     if (i < nP) {
@@ -342,7 +313,6 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) __attribute__((amdgpu_num_sgpr(GSR
     depth_out = o2y;
     q.radii[r] = radius;
     }
-    uint32_t wg_slots = 0u;  // gradient-record slots of this workgroup's Gaussians
     if (q.goff) {  // training workspace: the slot prefix the backward needs (gradient-record slots = bin-rect cells) falls out here
         __shared__ uint32_t s_w[GSR_BIN_THREADS / 64];
         const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -364,53 +334,10 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) __attribute__((amdgpu_num_sgpr(GSR
             tot += v;
         }
         if (i < q.P) q.goff[i] = woff + x - area;  // prefix inside this block of GSR_BIN_THREADS Gaussians
-        // (k_scan / the scan waves of the sort launch turn these into the prefix of the blocks)
-        if (tid == 0) q.gpart[blockIdx.x] = tot;
-        wg_slots = tot;
+        if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan / the scan waves of the sort launch turn these into the prefix of the blocks
     }
     // the exact ellipse/bin test of every cell of the rect is evaluated ONCE, here; the outcomes are kept as a bit mask
     // (cell k = row-major index inside the rect) that k_scatter reuses instead of re-testing every cell twice
-    if constexpr (DIRECT) {
-        __shared__ uint32_t d_cnt[GSR_BLOCK_TAB], d_base[GSR_BLOCK_TAB];
-        __shared__ int d_box[4];
-        uint32_t hitm = 0u, tested = 0u;
-        DirectHit dh;
-        dh.h = hit; dh.hitm = &hitm; dh.tested = &tested;
-        dh.x0 = rlo & 0xffff; dh.y0 = rlo >> 16; dh.w = (int)(rhi & 0xffff) - dh.x0;
-        const bool big = dh.w * ((int)(rhi >> 16) - dh.y0) > 32;
-        dh.rs.ok = 0;
-        if (big) dh.rs = gsr_rows_setup(hit);
-        dh.rows = dh.rs.ok && big;
-        const uint64_t key = ((uint64_t)__float_as_uint(depth_out) << 32) | (uint32_t)i;
-        const uint32_t cap_ = q.bin_cap;
-        uint64_t *keys = q.keys_direct;
-        // reserve: the value the count atomic returns IS the workgroup's base inside the bin's segment; an instance whose position falls beyond the
-        // segment is dropped here and the view is reported as an overflow by the scan waves of the sort launch (longest list > capacity)
-        // The view's totals fall out of the same atomics: R = sum of the counts reserved, and the longest list = the largest (base + count) any
-        // reservation saw (the last one to touch a bin sees its final length).  Every workgroup adds its share to one of GSR_ARRIVE_SHARDS accumulators
-        // (64 bytes apart: same-address device atomics retire at ~90 per microsecond, a single word measured +17 us on this kernel) with two
-        // fire-and-forget atomics; the first wave of the sort launch adds the shards up and publishes the header (also to the host).
-        __shared__ uint32_t d_tot[2];
-        if (threadIdx.x < 2) d_tot[threadIdx.x] = 0u;  // (ordered against the adds below by the barriers inside gsr_block_bin)
-        uint32_t my_inst = 0u, my_max = 0u;
-        auto reserve = [&](int bin, uint32_t cnt) {
-            const uint32_t base = atomicAdd(&bin_count[(size_t)bin * GSR_CPAD], cnt);
-            my_inst += cnt;
-            my_max = max(my_max, base + cnt);
-            return base;
-        };
-        gsr_block_bin<true, GSR_BIN_THREADS>(d_cnt, d_base, d_box, rlo, rhi, q.bx, dh, reserve, reserve,
-                                             [&](uint32_t pos, uint32_t, uint32_t bin) { if (pos < cap_) keys[(size_t)bin * cap_ + pos] = key; });
-        if (my_inst) { atomicAdd(&d_tot[0], my_inst); atomicMax(&d_tot[1], my_max); }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.arrive + 16u * (blockIdx.x % GSR_ARRIVE_SHARDS));
-            const unsigned long long add = (unsigned long long)d_tot[0] | ((unsigned long long)wg_slots << 32);  // {instances, slots}: < 2^32 each per view (or it overflows anyway)
-            if (add) atomicAdd(acc, add);
-            if (d_tot[1]) atomicMax(reinterpret_cast<uint32_t *>(acc + 1), d_tot[1]);
-        }
-        return;
-    }
     uint32_t mask = 0u;
     CountHit ch;
     ch.h = hit; ch.mask = &mask;
@@ -722,11 +649,8 @@ void gsr_launch_preprocess(const GsrFwdParams &p, GsrSplat *splats, uint4 *binre
     GsrFwdParams q = p;
     q.fx = (float)q.W / (2.f * q.tanfovx);  // (the same correctly-rounded fp32 division the kernel used to evaluate per thread)
     q.fy = (float)q.H / (2.f * q.tanfovy);
-    const bool appear = p.shs || p.cov3D_precomp, direct = p.bin_cap != 0u;
-    if (appear && direct) hipLaunchKernelGGL((k_preprocess<true, true>), grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
-    else if (appear) hipLaunchKernelGGL((k_preprocess<true, false>), grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
-    else if (direct) hipLaunchKernelGGL((k_preprocess<false, true>), grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
-    else hipLaunchKernelGGL((k_preprocess<false, false>), grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
+    if (p.shs || p.cov3D_precomp) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
+    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, q, splats, binrec, wg_tab, bin_count, bin_count_fb, hdr);
 }
 
 void gsr_launch_preprocess_bwd(const GsrBwdParams &p, const GsrSplat *splats, const uint32_t *goff, const uint32_t *gpart,

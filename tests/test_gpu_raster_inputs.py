@@ -288,19 +288,21 @@ def test_two_host_threads_through_the_compiled_host_path(monkeypatch):
                                                   torch.from_numpy(g["view"]).to(dev), torch.from_numpy(g["proj"]).to(dev), 3,
                                                   torch.from_numpy(g["campos"]).to(dev), False, False)
             gout = torch.from_numpy(np.random.default_rng(3).standard_normal((3, g["H"], g["W"])).astype(np.float32)).to(dev)
-            res = None
-            for _ in range(n):
+            res, fast = None, 0
+            for it in range(n):
                 t = {k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32)).to(dev).requires_grad_(True) for k in names}
                 m2 = torch.zeros_like(t["means3D"], requires_grad=True)
                 img, radii = RZ.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], colors_precomp=t["colors"],
                                                        scales=t["scales"], rotations=t["rotations"])
-                assert "CppNode" in img.grad_fn.name()
+                # (a view that outgrows the learnt capacity is handed to the Python path, which repairs it: the first of a scene may)
+                fast += "CppNode" in img.grad_fn.name()
                 img.backward(gout)
                 cur = [img.detach().clone(), radii.clone()] + [t[k].grad.clone() for k in names] + [m2.grad.clone()]
                 if res is not None:
                     assert all(torch.equal(a, b) for a, b in zip(res, cur))
                 res = cur
             torch.cuda.current_stream().synchronize()
+            assert fast >= n - 2, (fast, n)
             out.append(res)
 
     alone = []
