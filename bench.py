@@ -37,10 +37,10 @@ def stage_bytes(P, R, NB, npix, n_slots=None, n_rec=None, direct=False, color_gr
     """ALGORITHMIC bytes per launch of every stage (SURVEY.md section 8d convention: each input read once, each intermediate
     written once and read once, each output written once).  R = measured (Gaussian, 8x8-bin) instances, NB = bins, n_slots = gradient-record slots
     (bin-rect cells of all Gaussians), n_rec = slots the compositing backward wrote a record into (<= R).  Unknown counts fall back to R.
-    direct: direct bin lists (round 6) -- no scan / scatter launch, k_preprocess writes the keys, the sort launch carries the scan.
-      preprocess      scanned: 44 P in + 48 P splat record + 16 P bin record + 4 P radii + 8 P slot prefix = 120 P;  direct: 104 P + 8 R keys
+    direct: direct bin lists (round 6) -- no scan launch: the scatter needs no offsets, workgroups of its launch do what is left of the scan.
+      preprocess      44 P in + 48 P splat record + 16 P bin record + 4 P radii + 8 P slot prefix          = 120 P
       scan            8 NB counters in (two arrays) + 8 NB offsets / cursors + 4 NB work order            = 20 NB        (scanned lists only)
-      scatter         16 P bin records + 8 R keys                                                          = 16 P + 8 R   (scanned lists only)
+      scatter         16 P bin records + 8 R keys (+ direct: 8 NB counters in + 4 NB work order)           = 16 P + 8 R (+ 12 NB)
       sort            8 R keys in + 4 R ids out + 8 NB ranges / counts + work order                        = 12 R + 8 NB
       composite_fwd   4 R ids + 36 R splat record fields + 8 NB + 12 Npix image + 8 Npix state + n_slots flag bytes cleared
       composite_bwd   as the forward's reads + 12 Npix dL/dpix + 8 Npix state, + 37 B per record written (33 without colour sums: one sector + flag)
@@ -48,10 +48,11 @@ def stage_bytes(P, R, NB, npix, n_slots=None, n_rec=None, direct=False, color_gr
     n_slots = R if n_slots is None else n_slots
     n_rec = R if n_rec is None else n_rec
     rec_w, rec_r = (37, 36) if color_grad else (33, 32)
-    out = {"preprocess": (104 * P + 8 * R) if direct else 120 * P, "sort": 12 * R + 8 * NB, "composite_fwd": 40 * R + 8 * NB + 20 * npix + n_slots,
-           "composite_bwd": 40 * R + 8 * NB + 20 * npix + rec_w * n_rec, "preprocess_bwd": n_slots + rec_r * n_rec + 116 * P}
+    out = {"preprocess": 120 * P, "scatter": 16 * P + 8 * R + (12 * NB if direct else 0), "sort": 12 * R + 8 * NB,
+           "composite_fwd": 40 * R + 8 * NB + 20 * npix + n_slots, "composite_bwd": 40 * R + 8 * NB + 20 * npix + rec_w * n_rec,
+           "preprocess_bwd": n_slots + rec_r * n_rec + 116 * P}
     if not direct:
-        out.update(scan=20 * NB, scatter=16 * P + 8 * R)
+        out.update(scan=20 * NB)
     return out
 
 

@@ -181,14 +181,19 @@ __device__ __forceinline__ void gsr_bin_range(const GsrBins &b, uint32_t bin, ui
 struct GsrHit {
     float x, y, A, B, C, thr, rA, rC;
 };
+// 1 / x as ONE instruction (v_rcp_f32, 1 ulp) where the value only places the minimiser of a parabola along a bin edge: q is flat there, so an ulp of
+// the position is an ulp SQUARED of q, against a threshold inflated by 0.2 %.  The correctly rounded division (this library's compile flag) is ~12
+// instructions, twice per Gaussian in each of the VALU-bound kernels k_preprocess and k_scatter.  Deterministic: both passes execute the same instruction
+// on the same stored record.
+__device__ __forceinline__ float gsr_rcp_approx(float x) { return __builtin_amdgcn_rcpf(x); }
 // tau = logf(255 op), which the caller has computed already (a second logf() per Gaussian was ~25 vector instructions of a VALU-bound kernel)
 __device__ __forceinline__ GsrHit gsr_hit_setup(float x, float y, float A, float B, float C, float tau) {
     _Pragma("clang fp contract(off)")
     GsrHit h;
     h.x = x; h.y = y; h.A = A; h.B = B; h.C = C;
     h.thr = 2.f * tau * 1.002f + 0.02f;
-    h.rA = 1.f / A;
-    h.rC = 1.f / C;
+    h.rA = gsr_rcp_approx(A);
+    h.rC = gsr_rcp_approx(C);
     return h;
 }
 // The same test from a threshold that was computed elsewhere: k_scatter rebuilds the predicate of a Gaussian whose rect is too large for
@@ -201,8 +206,8 @@ __device__ __forceinline__ GsrHit gsr_hit_from_threshold(float x, float y, float
     GsrHit h;
     h.x = x; h.y = y; h.A = A; h.B = B; h.C = C;
     h.thr = thr;
-    h.rA = 1.f / A;
-    h.rC = 1.f / C;
+    h.rA = gsr_rcp_approx(A);
+    h.rC = gsr_rcp_approx(C);
     return h;
 }
 // minimum of the quadratic form over the rectangle of pixel centres [X0, X1] x [Y0, Y1] against the (inflated) threshold.

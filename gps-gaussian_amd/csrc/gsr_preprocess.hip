@@ -290,9 +290,12 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
                 // axis-aligned extent is |dx| <= sqrt(2 tau a), |dy| <= sqrt(2 tau c) with (a,b,c) the dilated 2D
                 // covariance.  Pairs outside can never pass the alpha test, so not listing them is exact; the box is
                 // inflated a little so that fp32 rounding in the compositing kernels can never disagree with it.
-                const float tau = logf(255.f * op);
+                // (v_log_f32 / v_sqrt_f32, 1 ulp each, instead of the library's logf and the correctly rounded square roots: ~70 vector instructions of a
+                //  VALU-bound kernel, for numbers that are inflated by 0.1 - 0.2 % before anything is decided with them.  log2(1) is exactly 0 and the
+                //  instruction is monotonic to its ulp, so the sign of tau -- opacity >= 1/255 -- is the exact one.)
+                const float tau = __builtin_amdgcn_logf(255.f * op) * 0.693147180559945f;
                 if (tau >= 0.f) {
-                    const float hx = sqrtf(2.f * tau * a) * 1.001f + 0.01f, hy = sqrtf(2.f * tau * c) * 1.001f + 0.01f;
+                    const float hx = __builtin_amdgcn_sqrtf(2.f * tau * a) * 1.001f + 0.01f, hy = __builtin_amdgcn_sqrtf(2.f * tau * c) * 1.001f + 0.01f;
                     int b0x = (int)floorf((px - hx) / 8.f), b1x = (int)floorf((px + hx) / 8.f) + 1;
                     int b0y = (int)floorf((py - hy) / 8.f), b1y = (int)floorf((py + hy) / 8.f) + 1;
                     b0x = max(b0x, 2 * r0x); b1x = min(b1x, min(2 * r1x, q.bx_real));
