@@ -419,7 +419,7 @@ __device__ __forceinline__ void scatter_totals_block(const ScDirect &d, uint32_t
     h->max_tile_count = tmax;
     h->num_slots = tot_slots;
     if (d.host_hdr) {  // as k_scan_b: write-through stores, acknowledged, then the sequence word the host polls
-        const uint32_t hv[7] = {(uint32_t)tsum, (uint32_t)(tsum >> 32), ovf_b ? 1u : 0u, tmax, 0u /* busy bins: known after the sort launch */, tot_slots, h->num_points};
+        const uint32_t hv[7] = {(uint32_t)tsum, (uint32_t)(tsum >> 32), ovf_b ? 1u : 0u, tmax, 0u /* busy bins: the scan waves of this launch are still counting them */, tot_slots, h->num_points};
 #pragma unroll
         for (int k = 0; k < 7; k++) __hip_atomic_store(d.host_hdr + k, hv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __builtin_amdgcn_s_waitcnt(0);

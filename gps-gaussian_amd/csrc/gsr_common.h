@@ -77,7 +77,7 @@ static_assert(sizeof(GsrGradAcc) == 32, "grad record must be exactly one 32-byte
 //   scanned lists (cap == 0): bin b owns [offset[b], offset[b + 1]) of keys / point_list -- the exclusive scan of the counts (k_scan_b);
 //   DIRECT lists (cap > 0, round 6): bin b owns [b * cap, b * cap + count[b] + count_fb[b]) -- a fixed-capacity segment per bin, so that an instance's slot
 //     follows from the base k_preprocess' count atomic returned without any offsets: the scatter pass needs no scan in front of it, and what is left
-//     of the scan (work order, slot prefix) leaves the critical path (it rides in the sort launch).  A view whose longest list exceeds cap is reported
+//     of the scan (totals, work order, slot prefix) leaves the critical path (it rides in the scatter launch).  A view whose longest list exceeds cap is reported
 //     as an overflow (header.max_tile_count > cap) and the caller repeats it with scanned lists.
 struct GsrBins {
     const uint32_t *offset, *count, *count_fb;  // (direct lists: a bin's length is count + count_fb -- the recorded workgroups' instances + the unrecorded ones')
@@ -118,7 +118,7 @@ static inline GsrLayout gsr_layout(int P, int W, int H, int64_t cap, uint32_t bi
     const size_t p = (size_t)(P > 0 ? P : 1), t = (size_t)(L.NB > 0 ? L.NB : 1), c = (size_t)(cap > 0 ? cap : 1);
     const size_t npix = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
     L.header = o;     o = gsr_align_up(o + sizeof(GsrHeader));   // header + scan_part + bin_count + bin_count_fb are zeroed by ONE memset
-    {   // two 64-bit words per scan block (+ padding); direct lists: two per scan WAVE of the sort launch (64 patch-order indices each) + one
+    {   // two 64-bit words per scan block (+ padding); direct lists: one per scan WAVE of the scatter launch (64 patch-order indices each)
         const size_t nt = (size_t)((L.bx + 7) / 8) * ((L.by + 7) / 8) * 64;
         const size_t nscan = ((nt > t ? nt : t) + 63) / 64;
         // direct lists: one word per scan wave of the scatter launch (whole workgroups of four)

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void k_preprocess(GsrFwdParams q, 
             tot += v;
         }
         if (i < q.P) q.goff[i] = woff + x - area;  // prefix inside this block of GSR_BIN_THREADS Gaussians
-        if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan / the scan waves of the sort launch turn these into the prefix of the blocks
+        if (tid == 0) q.gpart[blockIdx.x] = tot;   // k_scan_b / the scan waves of the direct lists' scatter launch turn these into the prefix of the blocks
     }
     // the exact ellipse/bin test of every cell of the rect is evaluated ONCE, here; the outcomes are kept as a bit mask
     // (cell k = row-major index inside the rect) that k_scatter reuses instead of re-testing every cell twice

@@ -57,8 +57,8 @@ def _hip_kat_render(scene):
 
 @pytest.fixture(params=["direct", "scanned"])
 def lists(request, monkeypatch):
-    """Both forms of the per-bin lists (include/gpsgs.h GsrViewExt.bin_capacity): DIRECT -- fixed-capacity segments filled by k_preprocess, scan riding in
-    the sort launch (round 6; what every view with short lists gets) -- and SCANNED -- k_scan_b + k_scatter + k_sort_* (long lists, large images)."""
+    """Both forms of the per-bin lists (include/gpsgs.h GsrViewExt.bin_capacity): DIRECT -- fixed-capacity segments, an offset-free scatter with the scan's
+    work beside it (round 6; what every view with short lists gets) -- and SCANNED -- k_scan_b + k_scatter + k_sort_* (long lists, large images)."""
     monkeypatch.setenv("GPSGS_LISTS", request.param)
     return request.param
 
@@ -1219,7 +1219,7 @@ def test_direct_lists_too_long_a_list_is_detected_repaired_with_scanned_lists_an
     RZ._state.clear()
 
 
-@pytest.mark.parametrize("scene", ["c1_256_30k", "cloud_big", "empty_borders"])
+@pytest.mark.parametrize("scene", ["c1_256_30k", "cloud_big", "empty_borders", "cloud_640x480_unrecorded_workgroups"])
 def test_direct_and_scanned_lists_give_identical_bits(scene, family, monkeypatch):
     """The two list forms differ in WHERE a bin's list lives and in which launch produces the work order -- never in what a list holds: after the
     per-bin sort both are the same ids in the same (depth, id) order, so image, radii, per-pixel state and every gradient must agree bit for bit.
@@ -1229,6 +1229,10 @@ def test_direct_and_scanned_lists_give_identical_bits(scene, family, monkeypatch
         g = S.make_scene(256, 30000)
     elif scene == "cloud_big":
         g = S.make_uniform_cloud(6000, 200, 120, seed=17, scale_med=0.04)
+    elif scene == "cloud_640x480_unrecorded_workgroups":
+        # 4,800 bins and Gaussians in random order: every binning workgroup's bin box is the whole image, larger than its LDS table -- its instances are
+        # counted band by band into the second counter array and placed behind the recorded ones through the cursors (direct lists: cursor = 0 + count)
+        g = S.make_uniform_cloud(9000, 640, 480, seed=19, scale_med=0.02)
     else:
         g = S.make_uniform_cloud(300, 517, 131, seed=18, scale_med=0.01)   # ragged grid edge, most bins empty
     dpix = np.random.default_rng(4).standard_normal((3, g["H"], g["W"])).astype(np.float32)

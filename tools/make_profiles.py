@@ -36,7 +36,7 @@ def main(d, tag):
                                  "# the untrained-heads regime (scales at their 0.01 m clamp: ~25 px splats, R ~ 3e7), one view at a time (bench.py's config3_regime leg renders the same scene)"], "regime_kernel_stats.md")
     names = {"k_composite_bwd": "composite_bwd", "k_composite_fwd": "composite_fwd", "k_composite_bwd_tiles": "composite_bwd", "k_composite_fwd_tiles": "composite_fwd",
              "k_preprocess": "preprocess", "k_preprocess_bwd": "preprocess_bwd", "k_scatter": "scatter", "k_sort_wave": "sort", "k_scan_b": "scan",
-             "k_sort_multi": "sort_multi", "k_sort_large": "sort_large", "k_sort_direct": "sort"}
+             "k_sort_multi": "sort_multi", "k_sort_large": "sort_large"}
 
     def traffic_json(agg_, workload, source, path):
         out_ = {"source": source, "workload": workload}
