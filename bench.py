@@ -41,16 +41,20 @@ def stage_bytes(P, R, NB, npix, n_slots=None, n_rec=None, direct=False, color_gr
       preprocess      44 P in + 48 P splat record + 16 P bin record + 4 P radii + 8 P slot prefix          = 120 P
       scan            8 NB counters in (two arrays) + 8 NB offsets / cursors + 4 NB work order            = 20 NB        (scanned lists only)
       scatter         16 P bin records + 8 R keys (+ direct: 8 NB counters in + 4 NB work order)           = 16 P + 8 R (+ 12 NB)
-      sort            8 R keys in + 4 R ids out + 8 NB ranges / counts + work order                        = 12 R + 8 NB
+      sort            8 R keys in + 4 R ids out + 8 NB ranges / counts + work order                        = 12 R + 8 NB  (direct lists + tile family: no such launch --
+                      the forward compositing waves sort their own lists, and these bytes are the forward's)
       composite_fwd   4 R ids + 36 R splat record fields + 8 NB + 12 Npix image + 8 Npix state + n_slots flag bytes cleared
       composite_bwd   as the forward's reads + 12 Npix dL/dpix + 8 Npix state, + 37 B per record written (33 without colour sums: one sector + flag)
       preprocess_bwd  n_slots flags + 36 n_rec records (32 without colour sums) + 40 P inputs + 8 P slot prefix + 68 P gradients"""
     n_slots = R if n_slots is None else n_slots
     n_rec = R if n_rec is None else n_rec
     rec_w, rec_r = (37, 36) if color_grad else (33, 32)
-    out = {"preprocess": 120 * P, "scatter": 16 * P + 8 * R + (12 * NB if direct else 0), "sort": 12 * R + 8 * NB,
-           "composite_fwd": 40 * R + 8 * NB + 20 * npix + n_slots, "composite_bwd": 40 * R + 8 * NB + 20 * npix + rec_w * n_rec,
+    fused_sort = direct and os.environ.get("GPSGS_COMPOSITE", "tiles") == "tiles" and os.environ.get("GPSGS_FUSED_SORT", "1") != "0"
+    out = {"preprocess": 120 * P, "scatter": 16 * P + 8 * R + (12 * NB if direct else 0),
+           "composite_fwd": 40 * R + 8 * NB + 20 * npix + n_slots + (12 * R if fused_sort else 0), "composite_bwd": 40 * R + 8 * NB + 20 * npix + rec_w * n_rec,
            "preprocess_bwd": n_slots + rec_r * n_rec + 116 * P}
+    if not fused_sort:
+        out.update(sort=12 * R + 8 * NB)
     if not direct:
         out.update(scan=20 * NB)
     return out

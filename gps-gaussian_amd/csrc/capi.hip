@@ -238,6 +238,10 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
     uint8_t *inst_valid_fwd = training ? reinterpret_cast<uint8_t *>(at(workspace, L.inst_valid)) : nullptr;
     const int n_gblocks = (P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS;
 
+    // direct lists + tile family: the forward compositing waves sort their own lists (no sort launch).  Not with the debug self-check, which inspects the
+    // sorted lists between the two; GPSGS_FUSED_SORT=0 keeps the separate launch (development: A/B timing)
+    static const bool fused_sort_env = [] { const char *e = getenv("GPSGS_FUSED_SORT"); return !(e && e[0] == '0'); }();
+    const bool fused_sort = bin_cap && (flags & GSR_FLAG_COMPOSITE_TILES) && fused_sort_env && !(trace_on() || (flags & GSR_FLAG_DEBUG));
     int rc;
     {
         trace("preprocess", P, width, height, (long long)instance_capacity, flags);
@@ -255,9 +259,11 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
                                       training ? reinterpret_cast<uint32_t *>(at(workspace, L.gprefix)) : nullptr, n_gblocks, wg_order, scan_part, order_hint, host_hdr, notify_seq, s);
         }
         if ((rc = check(s, flags)) != GPSGS_OK) return rc;
-        trace("sort (direct lists)", P, width, height, (long long)instance_capacity, flags);
-        StageTimer t(flags, GSR_STAGE_SORT, s);
-        gsr_launch_sort_direct(L.NB, bins, wg_order, keys, point_list, hdr, s);
+        if (!fused_sort) {
+            trace("sort (direct lists)", P, width, height, (long long)instance_capacity, flags);
+            StageTimer t(flags, GSR_STAGE_SORT, s);
+            gsr_launch_sort_direct(L.NB, bins, wg_order, keys, point_list, hdr, s);
+        }
     } else {
         {
             trace("scan", P, width, height, (long long)instance_capacity, flags);
@@ -314,7 +320,7 @@ extern "C" int gsr_forward_ex(int P, int width, int height, const float *means3D
         StageTimer t(flags, GSR_STAGE_COMPOSITE_FWD, s);
         if (flags & GSR_FLAG_COMPOSITE_TILES)
             gsr_launch_composite_fwd_tiles(width, height, L.bx, L.by, splats, bins, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, inst_valid_fwd, training,
-                                           (flags & GSR_FLAG_WAVE_PRIORITY) != 0, s);
+                                           (flags & GSR_FLAG_WAVE_PRIORITY) != 0, fused_sort ? keys : nullptr, s);
         else
             gsr_launch_composite_fwd(width, height, L.bx, L.by, splats, bins, wg_order, point_list, bg, out_color, final_T, n_contrib, hdr, inst_valid_fwd, s);
     }

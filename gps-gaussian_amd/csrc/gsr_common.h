@@ -515,10 +515,12 @@ static inline unsigned gsr_debug_lds_pad() {
 }
 // exponents from bf16 matrix-core tiles (gsr_composite_tiles.hip): same arguments, same results within rounding
 void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
-                                    const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr,
+                                    uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib, const GsrHeader *hdr,
                                     uint8_t *inst_valid /* training workspace: the record flags are cleared here; NULL otherwise */,
                                     bool keep_state /* false: inference workspace, final_T / n_contrib are not produced */,
-                                    bool wave_prio /* GSR_FLAG_WAVE_PRIORITY */, hipStream_t s);
+                                    bool wave_prio /* GSR_FLAG_WAVE_PRIORITY */,
+                                    const uint64_t *unsorted_keys /* direct lists: every wave sorts its own bin's list first (keys -> point_list); NULL: point_list is sorted */,
+                                    hipStream_t s);
 int gsr_set_wg_trace(unsigned long long *rows_device);  // development aid: per-workgroup timeline of the tile compositing kernels (NULL = off)
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
                                     const uint32_t *point_list, const float *bg, const float *dL_dpix, const float *final_T, const uint32_t *n_contrib,

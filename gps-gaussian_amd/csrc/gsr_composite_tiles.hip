@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "gsr_pow_tiles.h"
+#include "gsr_sort_wave.h"
 
 namespace {
 
@@ -111,13 +112,16 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
 #ifndef GSR_FWD_WAVES
 #define GSR_FWD_WAVES 5  // waves per SIMD asked of the compiler (92 VGPRs fit 5)
 #endif
-template <bool KEEP>
+// SORT (direct lists): the wave first sorts its own bin's list -- keys[r0, r1) -> point_list[r0, r1), one wave per list of <= 1,024 keys exactly as
+// k_sort_wave does it (gsr_sort_wave.h) -- and then walks it: no sort launch in front of the compositing.  The sorted ids go through global memory
+// (the backward needs them there anyway); the wave waits for its own stores before it reads them back.
+template <bool KEEP, bool SORT>
 __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             GsrBins bins, const uint32_t *__restrict__ wg_order,
-                                                            const uint32_t *__restrict__ point_list, const float *__restrict__ bg,
+                                                            uint32_t *point_list, const float *__restrict__ bg,
                                                             float *__restrict__ out_color, float *__restrict__ final_T,
                                                             uint32_t *__restrict__ n_contrib, const GsrHeader *__restrict__ hdr, uint8_t *__restrict__ inst_valid,
-                                                            int wave_prio) {
+                                                            int wave_prio, const uint64_t *__restrict__ keys) {
     __shared__ float4 sCol[WAVE];  // {opacity, r, g, b} of the 64 staged splats
     const WgTrace trace(blockIdx.x);
     const uint32_t list_pos = xcd_list_pos(blockIdx.x, hdr->num_busy_wgs);
@@ -129,6 +133,12 @@ __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W
     if (KEEP) clear_record_flags(inst_valid, hdr, g.lane, WAVE);
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);
     const int lane = g.lane;
+    if (SORT && r1 > r0) {  // (wave-uniform)
+        __shared__ uint32_t sIds[1024];
+        sort_wave_list(keys + r0, r1 - r0, point_list + r0, sIds, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave reads its own stores back: they must have left the vector memory queue
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     const float cx = (float)(g.px - (lane & 7)) + 3.5f, cy = (float)(g.py - (lane >> 3)) + 3.5f;  // bin centre
     const PowOperandsB opB = pow_operands_b(lane);
 
@@ -527,16 +537,16 @@ __global__ __launch_bounds__(64) void k_selftest_tiles(float *__restrict__ out) 
 }  // namespace
 
 void gsr_launch_composite_fwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,
-                                    const uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
-                                    const GsrHeader *hdr, uint8_t *inst_valid, bool keep_state, bool wave_prio, hipStream_t s) {
+                                    uint32_t *point_list, const float *bg, float *out_color, float *final_T, uint32_t *n_contrib,
+                                    const GsrHeader *hdr, uint8_t *inst_valid, bool keep_state, bool wave_prio, const uint64_t *unsorted_keys, hipStream_t s) {
     const int wgs = bx * by;
     if (wgs <= 0) return;
-    if (keep_state)
-        hipLaunchKernelGGL(k_composite_fwd_tiles<true>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list,
-                           bg, out_color, final_T, n_contrib, hdr, inst_valid, wave_prio ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_composite_fwd_tiles<false>, dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list,
-                           bg, out_color, final_T, n_contrib, hdr, nullptr, wave_prio ? 1 : 0);
+#define GSR_FWD_TILES_LAUNCH(KEEP_, SORT_)                                                                                                                       \
+    hipLaunchKernelGGL((k_composite_fwd_tiles<KEEP_, SORT_>), dim3(wgs), dim3(64), gsr_debug_lds_pad(), s, W, H, bx, splats, bins, wg_order, point_list, bg, out_color, \
+                       final_T, n_contrib, hdr, KEEP_ ? inst_valid : nullptr, wave_prio ? 1 : 0, unsorted_keys)
+    if (keep_state) { if (unsorted_keys) GSR_FWD_TILES_LAUNCH(true, true); else GSR_FWD_TILES_LAUNCH(true, false); }
+    else { if (unsorted_keys) GSR_FWD_TILES_LAUNCH(false, true); else GSR_FWD_TILES_LAUNCH(false, false); }
+#undef GSR_FWD_TILES_LAUNCH
 }
 
 void gsr_launch_composite_bwd_tiles(int W, int H, int bx, int by, const GsrSplat *splats, GsrBins bins, const uint32_t *wg_order,

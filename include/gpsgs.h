@@ -179,7 +179,8 @@ typedef struct GsrViewExt {
     /* ---- ABI 4: DIRECT bin lists.  0 = scanned lists (every earlier version).  > 0 (a multiple of 64, <= 1024; gsr_direct_lists_ok()): every 8x8-pixel bin
      *   owns a fixed-capacity segment of bin_capacity list entries, so an instance's slot follows from the base the count atomic of the preprocess returned
      *   without any offsets: the scatter needs no scan in front of it, and what is left of the scan (header, work order, slot prefix) rides in the scatter
-     *   launch -- four launches in front of the compositing instead of five, none of them a latency chain.  The workspace must be sized with gsr_workspace_bytes_ex(..., bin_capacity, ...); forward and backward of a view must
+     *   launch; with the tile compositing family the forward compositing waves sort their own lists, so there is no sort launch either -- three launches
+     *   in front of the compositing instead of five, none of them a latency chain.  The workspace must be sized with gsr_workspace_bytes_ex(..., bin_capacity, ...); forward and backward of a view must
      *   pass the same value.  A view whose longest list exceeds bin_capacity is NOT rendered: header.overflow = 1 with header.max_tile_count >
      *   bin_capacity -- repeat it with a larger capacity or with scanned lists (the capacity question upstream answers with a blocking read of R). */
     uint32_t bin_capacity;
