@@ -113,8 +113,8 @@ __device__ __forceinline__ void tiles_fwd_half(TileFwdState &st, const f32x16 &d
 #define GSR_FWD_WAVES 5  // waves per SIMD asked of the compiler (92 VGPRs fit 5)
 #endif
 // SORT (direct lists): the wave first sorts its own bin's list -- keys[r0, r1) -> point_list[r0, r1), one wave per list of <= 1,024 keys exactly as
-// k_sort_wave does it (gsr_sort_wave.h) -- and then walks it: no sort launch in front of the compositing.  The sorted ids go through global memory
-// (the backward needs them there anyway); the wave waits for its own stores before it reads them back.
+// k_sort_wave does it (gsr_sort_wave.h) -- and then walks it: no sort launch in front of the compositing.  The sorted ids go to global memory for the
+// backward and stay in LDS for this walk (first form: read back from global memory behind a wait for the wave's own stores).
 template <bool KEEP, bool SORT>
 __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W, int H, int bx, const GsrSplat *__restrict__ splats,
                                                             GsrBins bins, const uint32_t *__restrict__ wg_order,
@@ -133,11 +133,10 @@ __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W
     if (KEEP) clear_record_flags(inst_valid, hdr, g.lane, WAVE);
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r0), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.r1);
     const int lane = g.lane;
+    __shared__ uint32_t sIds[SORT ? 1024 : 1];
     if (SORT && r1 > r0) {  // (wave-uniform)
-        __shared__ uint32_t sIds[1024];
-        sort_wave_list(keys + r0, r1 - r0, point_list + r0, sIds, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave reads its own stores back: they must have left the vector memory queue
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        sort_wave_list(keys + r0, r1 - r0, point_list + r0, sIds, lane);  // the sorted ids: to global memory for the backward, and in sIds for this walk
+        sort_sync(true);
     }
     const float cx = (float)(g.px - (lane & 7)) + 3.5f, cy = (float)(g.py - (lane >> 3)) + 3.5f;  // bin centre
     const PowOperandsB opB = pow_operands_b(lane);
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA;
     float nC = 0.f;
     if (r0 + lane < r1) {  // prefetch round 0
-        const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[r0 + lane]);
+        const float4 *s = reinterpret_cast<const float4 *>(splats + (SORT ? sIds[lane] : point_list[r0 + lane]));
         nA = s[0]; nB = s[1]; nC = s[2].x;
     }
     for (uint32_t base = r0; base < r1; base += WAVE) {
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W
         const uint32_t nk = base + WAVE + lane;
         nB.y = 0.f;  // a slot without a splat blends nothing (opacity 0 -> alpha 0 < 1/255; stale x, y, conic stay finite)
         if (nk < r1) {  // prefetch the next round while this one is blended
-            const float4 *s = reinterpret_cast<const float4 *>(splats + point_list[nk]);
+            const float4 *s = reinterpret_cast<const float4 *>(splats + (SORT ? sIds[nk - r0] : point_list[nk]));
             nA = s[0]; nB = s[1]; nC = s[2].x;
         }
         const int cnt = (int)min((uint32_t)WAVE, r1 - base);

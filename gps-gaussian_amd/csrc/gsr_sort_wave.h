@@ -112,7 +112,7 @@ __device__ __forceinline__ void sort_stages_from(uint64_t (&key)[KPL], int lane)
 }
 
 template <int KPL>
-__device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, int lane) {
+__device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, uint32_t *ids, int lane) {
     constexpr int LOGK = KPL == 1 ? 0 : KPL == 2 ? 1 : KPL == 4 ? 2 : KPL == 8 ? 3 : 4;
     constexpr int LOGN = LOGK + 6;
     uint64_t key[KPL];
@@ -125,7 +125,7 @@ __device__ __forceinline__ void sort_wave_regs(const uint64_t *__restrict__ seg,
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const uint32_t e = (uint32_t)lane * KPL + r;
-        if (e < n) out[e] = (uint32_t)key[r];
+        if (e < n) { out[e] = (uint32_t)key[r]; ids[e] = (uint32_t)key[r]; }
     }
 }
 
@@ -279,9 +279,10 @@ __device__ __forceinline__ bool sort_wave_regs32(const uint64_t *__restrict__ se
     return true;
 }
 
-// one list of 1..1024 keys sorted by ONE wave, keys in registers (ids: 1,024 words of LDS)
+// one list of 1..1024 keys sorted by ONE wave, keys in registers (ids: 1,024 words of LDS).  On return out[0, n) AND ids[0, n) hold the sorted ids (a caller
+// that goes on to read ids[] synchronises the wave first: sort_sync(true)).
 __device__ __forceinline__ void sort_wave_list(const uint64_t *__restrict__ seg, uint32_t n, uint32_t *__restrict__ out, uint32_t *ids, int lane) {
-    if (n == 1u) { if (lane == 0) out[0] = (uint32_t)seg[0]; return; }
+    if (n == 1u) { if (lane == 0) { const uint32_t id = (uint32_t)seg[0]; out[0] = id; ids[0] = id; } return; }
     bool done;
     if (n <= 64u) done = sort_wave_regs32<1>(seg, n, out, ids, lane);
     else if (n <= 128u) done = sort_wave_regs32<2>(seg, n, out, ids, lane);
@@ -289,11 +290,11 @@ __device__ __forceinline__ void sort_wave_list(const uint64_t *__restrict__ seg,
     else if (n <= 512u) done = sort_wave_regs32<8>(seg, n, out, ids, lane);
     else done = sort_wave_regs32<16>(seg, n, out, ids, lane);
     if (done) return;  // (wave-uniform; otherwise: the exact 64-bit network below)
-    if (n <= 64u) sort_wave_regs<1>(seg, n, out, lane);
-    else if (n <= 128u) sort_wave_regs<2>(seg, n, out, lane);
-    else if (n <= 256u) sort_wave_regs<4>(seg, n, out, lane);
-    else if (n <= 512u) sort_wave_regs<8>(seg, n, out, lane);
-    else sort_wave_regs<16>(seg, n, out, lane);
+    if (n <= 64u) sort_wave_regs<1>(seg, n, out, ids, lane);
+    else if (n <= 128u) sort_wave_regs<2>(seg, n, out, ids, lane);
+    else if (n <= 256u) sort_wave_regs<4>(seg, n, out, ids, lane);
+    else if (n <= 512u) sort_wave_regs<8>(seg, n, out, ids, lane);
+    else sort_wave_regs<16>(seg, n, out, ids, lane);
 }
 
 }  // namespace
