@@ -412,9 +412,9 @@ def config_leg(res, gaussians, render_res, dev, steps, inflight, rs_proto, timed
 
 
 def full_pipeline_leg(budget_s):
-    """BASELINE configs 3 and 4 at full size, measured in THIS run: the reference's unmodified test_view_interp.py / train_stage2.Trainer (the bytecode build
-    oracle/stage_ref.py leaves in oracle/_ref; /root/reference is never read on the GPU box) with its real networks (random weights) on the drop-in
-    kernels, each once as the reference runs it and once with GPSGS_ACCELERATE=all (the opt-in import hook that lets the unmodified scripts reach the
+    """BASELINE configs 3 and 4 at full size, measured in THIS run WHERE A REFERENCE CHECKOUT EXISTS BESIDE THE GPU (nothing of the reference travels to
+    the GPU box since round 6, so on the driver's box this leg reports the recorded run of round 4 -- profiles/full_pipeline.json -- and says so): the
+    reference's unmodified test_view_interp.py / train_stage2.Trainer with its real networks (random weights) on the drop-in kernels, each once as the reference runs it and once with GPSGS_ACCELERATE=all (the opt-in import hook that lets the unmodified scripts reach the
     fused pack / loss / corr / upsample / unproject kernels).  MIOpen's exhaustive convolution search takes ~5 minutes on a fresh box, so the children
     run with MIOPEN_FIND_MODE=FAST (unless the caller set one): the networks are then ~15 % slower than with the default find mode -- the builder's
     default-find-mode numbers are replayed next to these, labelled.  Anything that does not fit the time budget is skipped and says so."""
@@ -427,7 +427,7 @@ def full_pipeline_leg(budget_s):
     except Exception as e:  # noqa: BLE001
         return {"measured_in_this_run": False, "skipped": "tools/refenv.py unavailable: %r" % (e,)}
     if ref is None:
-        return {"measured_in_this_run": False, "skipped": "no reference build (oracle/_ref/GPS-Gaussian is staged by __graft_entry__.build() where /root/reference exists)"}
+        return {"measured_in_this_run": False, "skipped": "no reference checkout on this machine (nothing of the reference travels to the GPU box)"}
     env = dict(os.environ)
     env.setdefault("MIOPEN_FIND_MODE", "FAST")
     env.pop("GPSGS_ACCELERATE", None)
@@ -844,7 +844,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- the full pipeline: BASELINE configs 3 / 4 with the reference's OWN scripts and networks, MEASURED IN THIS RUN -------------------------
-    # (rank 0, N = 1; the reference build under oracle/_ref is the CALLER of the product here, executed by tools/run_reference.py in child processes)
+    # (rank 0, N = 1; where a reference checkout exists it is the CALLER of the product here, executed by tools/run_reference.py in child processes)
     full_pipeline = None
     D.restore_affinity()  # (a no-op unless pin_near_gpu() pinned this rank: everything below is CPU-heavy or runs in child processes)
     el_unpinned = elapsed  # (`value` itself is the unpinned figure since round 6)

@@ -4,7 +4,7 @@ GPSGS_ACCELERATE asks for it, with the reference's modules loaded UNMODIFIED fro
 Each case runs in a fresh interpreter with the integration path (dropin ahead of the reference) and imports the reference's real
 `train_stage2.py` / `test_view_interp.py` as modules: the import ORDER of those files (train_stage2.py:12-17: lib.human_loader, lib.network ->
 core.raft_stereo_human -> core.corr -> `import corr_sampler` (the hook goes in here), ..., lib.GaussianRender, lib.loss) is what the hook has to cope
-with.  The reference is the checkout in the build container, the bytecode build of it (oracle/_ref) elsewhere."""
+with.  The reference is the checkout in the build container; the tests skip where there is none."""
 import os
 import subprocess
 import sys
@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import refenv  # noqa: E402
 
 REF = refenv.reference_dir()
-pytestmark = pytest.mark.skipif(REF is None, reason="no reference (neither /root/reference nor oracle/_ref)")
+pytestmark = pytest.mark.skipif(REF is None, reason="no reference checkout here")
 
 _PRELUDE = """
 import os, sys

@@ -1,8 +1,9 @@
 """GPU (-m gpu): the reference's OWN code, unmodified, executing on the HIP kernels of an MI355X.
 
-The reference comes from tools/refenv.reference_dir(): /root/reference in the build container, on the GPU box the bytecode build that
-oracle/stage_ref.py leaves in the git-ignored oracle/_ref/GPS-Gaussian (it travels with the snapshot like the built .so files).  Every
-check runs in a fresh interpreter whose sys.path holds gps-gaussian_amd/dropin ahead of the reference -- the whole integration of
+The reference comes from tools/refenv.reference_dir(): a CHECKOUT (--reference, $GPSGS_REFERENCE, /root/reference).  Nothing of the reference travels
+to the GPU box (through round 5 a sourceless-bytecode build did: the runs of rounds 3-5 are recorded in profiles/r0[345]_full_pipeline.md,
+profiles/full_pipeline.json and the parity reports; since round 6 it no longer does), so these tests SKIP there and run where a checkout and an MI355X
+coexist.  Every check runs in a fresh interpreter whose sys.path holds gps-gaussian_amd/dropin ahead of the reference -- the whole integration of
 INTEGRATION.md -- and calls the reference's functions on cuda:0:
 
   * lib/GaussianRender.py:6-40 `pts2render` -> gaussian_renderer/__init__.py:17-67 `render` -> the drop-in `diff_gaussian_rasterization`:
@@ -30,7 +31,7 @@ import refenv  # noqa: E402
 
 REF = refenv.reference_dir()
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(REF is None, reason="no reference: neither /root/reference nor oracle/_ref/GPS-Gaussian (python oracle/stage_ref.py)")]
+              pytest.mark.skipif(REF is None, reason="no reference checkout here (nothing of the reference travels to the GPU box)")]
 
 _PRELUDE = """
 import json, math, os, sys

@@ -99,17 +99,10 @@ HOOK = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("form", ["checkout", "staged-bytecode", "checkout-eval-inside-the-run", "checkout-stock-ddp", "checkout-stock-ddp-eval-inside-the-run"])
+@pytest.mark.parametrize("form", ["checkout", "checkout-eval-inside-the-run", "checkout-stock-ddp", "checkout-stock-ddp-eval-inside-the-run"])
 def test_launcher_trains_the_reference_trainer_data_parallel(tmp_path, form):
     ref = REF
     eval_freq = 2 if form.endswith("eval-inside-the-run") else 1000
-    if form == "staged-bytecode":     # what the GPU box has: oracle/stage_ref.py's build of the reference (sourceless .pyc + YAML)
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        try:
-            import stage_ref
-        finally:
-            sys.path.pop(0)
-        ref = stage_ref.stage(REF, str(tmp_path / "GPS-Gaussian"), quiet=True)
     hook = tmp_path / "hook.py"
     hook.write_text(HOOK)
     out = tmp_path / "result.json"

@@ -111,8 +111,7 @@ def _install_timing(TS, trainer, torch):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
-    ap.add_argument("--reference", default=None, help="checkout of aipixel/GPS-Gaussian (unmodified); default: /root/reference, else the bytecode build "
-                                                      "oracle/stage_ref.py leaves in oracle/_ref/GPS-Gaussian")
+    ap.add_argument("--reference", default=None, help="checkout of aipixel/GPS-Gaussian (unmodified); default: $GPSGS_REFERENCE, /root/reference")
     ap.add_argument("--config", default="config/stage2.yaml", help="relative to the working directory (--workdir, default: the reference)")
     ap.add_argument("--workdir", default=None, help="cwd for the reference's cwd-relative paths: a scratch directory made by tools/refenv.make_workdir "
                                                     "(links to the reference + its own config/stage2.yaml); default: the reference itself")
@@ -144,7 +143,7 @@ def main(argv=None):
 
     ref = refenv.reference_dir(args.reference)
     if ref is None:
-        raise SystemExit("launch_stage2: no reference checkout (looked at --reference, $GPSGS_REFERENCE, /root/reference, oracle/_ref/GPS-Gaussian)")
+        raise SystemExit("launch_stage2: no reference checkout (looked at --reference, $GPSGS_REFERENCE, /root/reference)")
     rank, local_rank, world = D.env_rank()
     use_cuda = torch.cuda.is_available()
     if use_cuda:

@@ -37,8 +37,8 @@ def main(d, tag, bench_json):
     out = {"measured_on": "one MI355X (gpurun), random-init network weights, synthetic THuman-like data set on disk (tools/make_synthetic_dataset.py), round 4",
            "command_config4": "python tools/run_reference.py ddp --res 1024 --steps 16 --batch 4 --train-samples 4 [--accelerate all]   (MIOpen default find mode)"}
     md = ["# BASELINE configs 3 and 4: the reference's OWN scripts, unmodified, on the HIP drop-in (one MI355X) -- as the reference runs them, and with the import hook", "",
-          "The reference (`test_view_interp.py`, `train_stage2.py`, its networks, data-set class, losses) is the bytecode build `oracle/stage_ref.py` leaves in the git-ignored",
-          "`oracle/_ref/GPS-Gaussian`; `tools/run_reference.py` executes the scripts as `__main__` / drives `tools/launch_stage2.py` with `gps-gaussian_amd/dropin` ahead on",
+          "The reference (`test_view_interp.py`, `train_stage2.py`, its networks, data-set class, losses) is a checkout beside the GPU (rounds 3-5: a bytecode build that",
+          "travelled to the GPU box; removed in round 6); `tools/run_reference.py` executes the scripts as `__main__` / drives `tools/launch_stage2.py` with `gps-gaussian_amd/dropin` ahead on",
           "`sys.path`.  Weights are RANDOM (no checkpoint offline) and the data set is synthetic: the regressed scales sit at their 0.01 m clamp, ~3e7 (Gaussian, bin) instances per",
           "2048^2 view.  **as the reference runs it** = only the two external extensions are replaced (rows a1-a14).  **GPSGS_ACCELERATE=all** = the opt-in import hook",
           "(`gps-gaussian_amd/accelerate.py`) additionally rebinds the reference's `pts2render`, `l1_loss` / `ssim`, `CorrBlockFast1D`, `upsample_flow`, `flow2depth` / `depth2pc` to the",

@@ -1,8 +1,8 @@
 """Harness around the UNMODIFIED reference scripts (tools/launch_stage2.py, tools/run_reference.py, the -m gpu reference tests).
 
 Nothing here is product code and nothing of the reference is edited.  What it provides:
-  * `reference_dir()`: where the reference lives -- /root/reference in the build container, else the bytecode build of it that
-    oracle/stage_ref.py leaves in the git-ignored oracle/_ref/GPS-Gaussian (that is what exists on the GPU box);
+  * `reference_dir()`: where the reference lives -- --reference, $GPSGS_REFERENCE or /root/reference (a checkout: nothing of the reference travels to
+    the GPU box, so what needs it runs only where a checkout exists);
   * `install_shims()`: stand-ins for yacs / cv2 / tensorboard, only when the real packages are missing;
   * `pythonpath()`: the whole integration -- gps-gaussian_amd/dropin (the MI355X rasteriser / correlation sampler under the
     reference's import names) ahead of the reference on sys.path;
@@ -19,13 +19,12 @@ from pathlib import Path
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-STAGED = os.path.join(ROOT, "oracle", "_ref", "GPS-Gaussian")
 DROPIN = os.path.join(ROOT, "gps-gaussian_amd", "dropin")
 SHIMS = os.path.join(HERE, "shims")
 
 
 def reference_dir(explicit=None):
-    for p in (explicit, os.environ.get("GPSGS_REFERENCE"), "/root/reference", STAGED):
+    for p in (explicit, os.environ.get("GPSGS_REFERENCE"), "/root/reference"):
         if p and os.path.isdir(p) and (os.path.exists(os.path.join(p, "train_stage2.py")) or os.path.exists(os.path.join(p, "train_stage2.pyc"))):
             return os.path.abspath(p)
     return None

@@ -5,8 +5,8 @@
     python tools/run_reference.py real [--samples 2] [--ratio 0.5] [--res 1024]       test_real_data.py     (one novel view per frame)
     python tools/run_reference.py train  [--steps 12] [--batch 2] [--res 1024]       train_stage2.py       (config 4, one process)
 
-The reference is found by tools/refenv.reference_dir(): /root/reference in the build container, the bytecode build in the git-ignored
-oracle/_ref/GPS-Gaussian (oracle/stage_ref.py) on the GPU box.  The script is executed as `__main__` by runpy -- the same code object
+The reference is found by tools/refenv.reference_dir(): --reference, $GPSGS_REFERENCE or /root/reference -- a CHECKOUT (nothing of the reference
+travels to the GPU box: this tool runs where a checkout and an MI355X coexist).  The script is executed as `__main__` by runpy -- the same code object
 `python test_view_interp.py ...` would run -- from a scratch working directory (tools/refenv.make_workdir) with
 gps-gaussian_amd/dropin ahead of the reference on sys.path.  What the harness supplies, and nothing else:
   * a synthetic data set in the loader's on-disk layout (tools/make_synthetic_dataset.py) -- the reference's real
@@ -82,7 +82,7 @@ def interp(args):
 
     ref = refenv.reference_dir(args.reference)
     if ref is None:
-        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+        raise SystemExit("run_reference: no reference checkout (--reference, $GPSGS_REFERENCE, /root/reference)")
     refenv.activate(ref)
     work = os.path.abspath(args.work)
     data_root = _dataset(work, args.res, 0, args.samples, args.fill)
@@ -203,7 +203,7 @@ def real(args):
 
     ref = refenv.reference_dir(args.reference)
     if ref is None:
-        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+        raise SystemExit("run_reference: no reference checkout (--reference, $GPSGS_REFERENCE, /root/reference)")
     refenv.activate(ref)
     work = os.path.abspath(args.work)
     data_root = _dataset(work, args.res, 0, args.samples, args.fill)
@@ -251,7 +251,7 @@ def train(args):
 
     ref = refenv.reference_dir(args.reference)
     if ref is None:
-        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+        raise SystemExit("run_reference: no reference checkout (--reference, $GPSGS_REFERENCE, /root/reference)")
     refenv.activate(ref)
     work = os.path.abspath(args.work)
     data_root = _dataset(work, args.res, args.train_samples, 2, args.fill)
@@ -311,7 +311,7 @@ def ddp(args):
 
     ref = refenv.reference_dir(args.reference)
     if ref is None:
-        raise SystemExit("run_reference: no reference (neither /root/reference nor oracle/_ref/GPS-Gaussian; run oracle/stage_ref.py)")
+        raise SystemExit("run_reference: no reference checkout (--reference, $GPSGS_REFERENCE, /root/reference)")
     work = os.path.abspath(args.work)
     rank = int(os.environ.get("RANK", "0"))
     if rank == 0:
