@@ -8,8 +8,8 @@ rows = [json.loads(l) for l in open(os.path.join(root, "gpurun_out", "parity_rep
 rows = list({r["test"]: r for r in rows}.values())  # (a test that ran twice -- a re-run of part of the suite -- counts once: its last run)
 L = ["# Parity report of the GPU suite (`python -m pytest tests -m gpu`, MI355X): HIP path vs the fp32 C oracle on the same inputs.",
      "# Source: gpurun_out/parity_report.jsonl (tests/conftest.py::parity_report), formatted by tools/make_parity_report.py.",
-     "# (Rows of test_gpu_reference.py -- the reference's own pts2render on the kernels -- need a reference checkout beside the GPU: they were recorded while a bytecode build of the",
-     "#  reference still travelled to the GPU box, which stopped in round 6; they skip on the driver's box now.)",
+     "# (test_gpu_reference.py -- the reference's own pts2render on the kernels -- needs a reference checkout beside the GPU: nothing of the reference travels to the GPU box since",
+     "#  round 6, so those tests skip there and this report has no rows of them; profiles/r05_parity_report.md holds the last recorded ones.)",
      "# fragile = pixels within 1e-5 (relative) of an alpha / transmittance threshold in the oracle, or holding a pair whose exponent is within 1e-6 of upstream's",
      "# `power > 0` skip (the tile family evaluates the exponent exactly and never skips: INTEGRATION.md section 3).  'touched' = Gaussians that TAKE PART in a fragile pixel",
      "# (alpha >= 1/255 there, inside their tile rect, in front of a clear stop: oracle/gsr_oracle.c flip_bound) -- round 5; until round 4 it was every Gaussian whose radius + 1",
