@@ -1273,3 +1273,34 @@ def test_direct_lists_record_slot_overflow_is_repaired(monkeypatch):
     for k in grads:
         np.testing.assert_array_equal(grads[k], g_ref[k], err_msg=k)
 
+
+
+@pytest.mark.parametrize("scene", ["c1_256_30k", "cloud_640x480", "stack_deep"])
+def test_sort_inside_the_forward_compositing_matches_the_sort_launch(scene, monkeypatch):
+    """Direct lists + tile family: the forward compositing wave sorts its own bin's list (no sort launch).  debug=True keeps the separate k_sort_wave launch
+    (the self-check inspects the sorted lists between the two): image, radii, per-pixel state, the sorted lists the backward reads and every gradient must be
+    the same bits either way."""
+    from gps_gaussian_amd import rasterizer as RZ, synthetic as S
+    monkeypatch.setenv("GPSGS_COMPOSITE", "tiles")
+    monkeypatch.setenv("GPSGS_LISTS", "direct")
+    if scene == "c1_256_30k":
+        g = S.make_scene(256, 30000)
+    elif scene == "cloud_640x480":
+        g = S.make_uniform_cloud(9000, 640, 480, seed=19, scale_med=0.02)
+    else:
+        g = _stack_scene(4000, 9)     # lists of several hundred keys with many equal-depth runs to put in id order
+    dpix = np.random.default_rng(8).standard_normal((3, g["H"], g["W"])).astype(np.float32)
+    out = []
+    for debug in (False, True):
+        img, radii, grads, info = hip_render(g, dpix, debug=debug)
+        assert info["bin_cap"] > 0
+        st = RZ.export_state(info["ws"], g["means3D"].shape[0], g["W"], g["H"], info["cap"], info["bin_cap"])
+        rg, pl = st["ranges"].cpu().numpy(), st["point_list"].cpu().numpy()
+        out.append((img, radii, grads, st["n_contrib"].cpu().numpy(), st["final_T"].cpu().numpy(), [pl[a:b].copy() for a, b in rg]))
+    a, b = out
+    np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+    assert len(a[5]) == len(b[5]) and all(np.array_equal(x, y) for x, y in zip(a[5], b[5]))
+    assert max(len(x) for x in a[5]) > 64
+    for k in a[2]:
+        np.testing.assert_array_equal(a[2][k], b[2][k], err_msg=k)
