@@ -115,7 +115,7 @@ typedef struct GsrHeader {      /* first bytes of the workspace, device memory *
     uint32_t num_slots;         /* training workspaces only: bin-rect cells of all Gaussians (one gradient-record slot each); also <= capacity */
     uint32_t num_points;        /* Gaussians of this view: P, or end - begin of GsrViewExt.row_range */
     uint32_t row_overflow;      /* 1 if a row range held more rows than the P (= row capacity) the call was made with: reported as overflow */
-    uint32_t reserved[8];
+    uint32_t reserved[8];       /* scratch of the library (direct lists: the accumulators of the totals workgroups); zeroed by every forward */
 } GsrHeader;
 
 /* direct lists (GsrViewExt.bin_capacity): 1 if this image size and capacity can use them (capacity a multiple of 64 in 64..1024, at most 65,536 bins) */
