@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64, GSR_FWD_WAVES) void k_composite_fwd_tiles(int W
     const int lane = g.lane;
     __shared__ uint32_t sIds[SORT ? 1024 : 1];
     if (SORT && r1 > r0) {  // (wave-uniform)
+        if (wave_prio) prio_by_remaining(r1 - r0, hdr->max_tile_count);  // the longest lists sort first and start their walks while the short ones still sort
         sort_wave_list(keys + r0, r1 - r0, point_list + r0, sIds, lane);  // the sorted ids: to global memory for the backward, and in sIds for this walk
         sort_sync(true);
     }
