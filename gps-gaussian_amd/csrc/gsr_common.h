@@ -311,7 +311,8 @@ __device__ __forceinline__ GsrMaskedHit gsr_masked_hit(const GsrHit &h, uint32_t
     m.x0 = lo & 0xffff; m.y0 = lo >> 16; m.w = (int)(hi & 0xffff) - m.x0;
     const int area = m.w * ((int)(hi >> 16) - m.y0);
     m.big = area > 32;
-    m.rs = gsr_rows_setup(h);
+    m.rs.ok = 0;
+    if (m.big) m.rs = gsr_rows_setup(h);  // (a division and a square root nobody needs for the ~4-cell rects of trained scales: k_preprocess skips them the same way)
     m.rows = m.big && m.rs.ok;
     return m;
 }
