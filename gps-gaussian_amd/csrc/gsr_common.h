@@ -338,12 +338,18 @@ __device__ __forceinline__ void gsr_block_bin(uint32_t *s_cnt, uint32_t *s_base,
     const bool has = (x1 > x0) && (y1 > y0);
     __syncthreads();  // (a previous call's tables are done with)
     if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
-    int mnx = has ? x0 : 0x7fffffff, mny = has ? y0 : 0x7fffffff, mxx = has ? x1 : -1, mxy = has ? y1 : -1;
+    // the wave's bin box: {min x, min y} and {max x, max y} as two PACKED pairs of 16-bit numbers (bin coordinates stay below 8,192): 12 lane exchanges and 12
+    // v_pk_min / v_pk_max_i16 instead of 24 + 24 -- ~4 % of a VALU-bound kernel's instructions (round 6)
+    typedef short gsr_s16x2 __attribute__((ext_vector_type(2)));
+    gsr_s16x2 mn = {(short)(has ? x0 : 0x7fff), (short)(has ? y0 : 0x7fff)}, mx = {(short)(has ? x1 : -1), (short)(has ? y1 : -1)};
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, d, 64)); mny = min(mny, __shfl_xor(mny, d, 64));
-        mxx = max(mxx, __shfl_xor(mxx, d, 64)); mxy = max(mxy, __shfl_xor(mxy, d, 64));
+        const gsr_s16x2 on = __builtin_bit_cast(gsr_s16x2, __shfl_xor(__builtin_bit_cast(int, mn), d, 64));
+        const gsr_s16x2 ox = __builtin_bit_cast(gsr_s16x2, __shfl_xor(__builtin_bit_cast(int, mx), d, 64));
+        mn = __builtin_elementwise_min(mn, on);
+        mx = __builtin_elementwise_max(mx, ox);
     }
+    const int mnx = mn.x, mny = mn.y, mxx = mx.x, mxy = mx.y;
     __syncthreads();
     if (lane == 0 && mxx >= 0) {
         atomicMin(&s_box[0], mnx); atomicMin(&s_box[1], mny); atomicMax(&s_box[2], mxx); atomicMax(&s_box[3], mxy);
